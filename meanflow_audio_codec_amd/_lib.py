@@ -1,0 +1,94 @@
+"""ctypes binding of the C-ABI HIP library (``include/mfc.h``).
+
+PyTorch is used only for device memory and streams.  There is NO fallback:
+if ``libmfc.so`` is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import pathlib
+import re
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch  # noqa: F401  (loads the ROCm runtime libmfc.so links against)
+
+_HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _HERE / "csrc" / "libmfc.so"
+HEADER = _HERE.parent / "include" / "mfc.h"
+
+MFC_F32, MFC_BF16 = 0, 1
+GEMM_TRANS_A, GEMM_TRANS_B, GEMM_ACCUM, GEMM_GELU = 1, 2, 4, 8
+
+_ERR = {-22: "MFC_EINVAL (bad shape/argument)", -38: "MFC_ENOSYS (unsupported)",
+        -14: "MFC_EFAULT (null pointer)", -5: "MFC_EHIP (HIP launch error)"}
+
+
+class MfcError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes); kept in sync with include/mfc.h by
+# tests/test_capi_symbols.py
+_P = c_void_p
+SIGNATURES = {
+    "mfc_abi_version": (c_int, []),
+    "mfc_build_info": (c_char_p, []),
+    "mfc_mdct_num_frames": (c_int64, [c_int64, c_int, c_int]),
+    "mfc_mdct_out_len": (c_int64, [c_int64, c_int, c_int]),
+    "mfc_mdct_fwd": (c_int, [_P, c_int64, c_int64, c_int64, c_int, c_int, _P, _P]),
+    "mfc_mdct_inv": (c_int, [_P, c_int64, c_int64, c_int, c_int, _P, c_int64, _P]),
+    "mfc_gemm": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64,
+                         _P, c_int64, c_int64, c_float, _P, c_int64, c_float, c_int, _P, _P]),
+}
+
+
+def header_symbols() -> list[str]:
+    """Every function declared in include/mfc.h."""
+    txt = HEADER.read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mfc_[a-z0-9_]+)\s*\(", txt)))
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise MfcError(
+                f"{LIB_PATH} not found: build it with `python -m meanflow_audio_codec_amd._build` "
+                "(there is no CPU fallback for the HIP path)")
+        l = ctypes.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise MfcError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return MFC_F32
+    if dt == torch.bfloat16:
+        return MFC_BF16
+    raise MfcError(f"unsupported dtype {dt}")
+
+
+def require_cuda(*ts) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise MfcError("HIP path needs device tensors (no CPU fallback); got a CPU tensor")
+
+
+def ptr(t) -> int | None:
+    return None if t is None else t.data_ptr()

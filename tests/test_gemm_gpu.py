@@ -1,0 +1,85 @@
+"""GPU numerics: mfc_gemm (MFMA) vs torch fp64 matmul on the same inputs."""
+import itertools
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(A, B, ta, tb, bias, bias_rows, alpha, R, beta):
+    A64 = (A.t() if ta else A).double()
+    B64 = (B.t() if tb else B).double()
+    C = A64 @ B64
+    if bias is not None:
+        C[:bias_rows] += bias.double()[None, :]
+    C = alpha * C
+    if R is not None:
+        C = C + beta * R.double()
+    return C
+
+
+SHAPES = [(128, 128, 32), (4, 16, 20), (130, 257, 100), (256, 384, 96), (37, 515, 1030), (300, 64, 4099),
+          (1, 1, 1), (129, 129, 33)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ta,tb", list(itertools.product([False, True], repeat=2)))
+def test_gemm_all_layouts(dtype, ta, tb):
+    from meanflow_audio_codec_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for (M, N, K) in SHAPES:
+        A = torch.randn((K, M) if ta else (M, K), generator=g, device="cuda").to(dtype)
+        B = torch.randn((N, K) if tb else (K, N), generator=g, device="cuda").to(dtype)
+        bias = torch.randn(N, generator=g, device="cuda")
+        R = torch.randn(M, N, generator=g, device="cuda").to(dtype)
+        C = ops.gemm(A, B, trans_a=ta, trans_b=tb, bias=bias, bias_rows=max(1, M // 2), alpha=0.5,
+                     residual=R, beta=2.0)
+        ref = _ref(A, B, ta, tb, bias, max(1, M // 2), 0.5, R, 2.0)
+        err = (C.double() - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        tol = (2e-6 if dtype == torch.float32 else 1e-2) * max(scale, 1.0)
+        assert err <= tol, (M, N, K, ta, tb, dtype, err, scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_splitk_gelu_tangent_rows(dtype):
+    """Row-stacked [x; xdot]: primal rows get bias + GELU, tangent rows t*gelu'(pre)."""
+    from meanflow_audio_codec_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(1)
+    Rr, K, N = 24, 5000, 128
+    X = torch.randn(2 * Rr, K, generator=g, device="cuda").to(dtype) * 0.05
+    W = torch.randn(K, N, generator=g, device="cuda").to(dtype)
+    b = torch.randn(N, generator=g, device="cuda")
+    for splitk in (1, 7, 64):
+        C = ops.gemm(X, W, bias=b, bias_rows=Rr, gelu=True, act_rows=Rr, splitk=splitk)
+        x64 = X.double().requires_grad_(False)
+        pre = x64[:Rr] @ W.double() + b.double()
+        tan = x64[Rr:] @ W.double()
+        prim = torch.nn.functional.gelu(pre, approximate="tanh")
+        pre_g = pre.clone().requires_grad_(True)
+        (torch.nn.functional.gelu(pre_g, approximate="tanh")).backward(torch.ones_like(pre_g))
+        ref = torch.cat([prim, tan * pre_g.grad], 0)
+        err = (C.double() - ref).abs().max().item()
+        tol = 2e-5 if dtype == torch.float32 else 3e-2
+        assert err <= tol * max(1.0, ref.abs().max().item()), (splitk, dtype, err)
+
+
+def test_gemm_accumulate_and_strides():
+    from meanflow_audio_codec_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(2)
+    A = torch.randn(70, 200, generator=g, device="cuda")[:, :150]   # lda=200, K=150
+    B = torch.randn(150, 90, generator=g, device="cuda")[:, 3:80]   # unaligned base -> scalar loads
+    B = B if B.stride(1) == 1 else B.contiguous()
+    C0 = torch.randn(70, 77, generator=g, device="cuda")
+    C = C0.clone()
+    ops.gemm(A, B, out=C, accumulate=True)
+    ref = C0.double() + A.double() @ B.double()
+    assert (C.double() - ref).abs().max().item() < 1e-4
+
+
+def test_gemm_rejects_cpu_tensors():
+    from meanflow_audio_codec_amd import ops
+    from meanflow_audio_codec_amd._lib import MfcError
+    with pytest.raises(MfcError):
+        ops.gemm(torch.zeros(4, 4), torch.zeros(4, 4))
