@@ -96,6 +96,147 @@ int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
              float alpha, const void* R, int64_t ldr, float beta_res,
              int splitk, float* ws, void* stream);
 
+/* ------------------------------------------------------------------ */
+/* ConvNeXt block interior (models/conv_flow.py:65-115,162-186)        */
+/* ------------------------------------------------------------------ */
+/* The spatial part of ConditionalConvNeXtBlock, between input_proj2 and
+ * output_proj1, on NHWC maps h0 [R, s, s, 16] (R = rows of the row-stacked
+ * batch; channel count C = min(16, cond/4) = 16 for every shipped config,
+ * other C -> MFC_ENOSYS):
+ *   h2 = (1+scale) * LN_C(h0) + shift                 conv_flow.py:181-186
+ *   c1 = Conv3x3_SAME(h2) ; n1 = LN_C(c1)             conv_flow.py:74-84
+ *   g1 = gelu(Conv1x1_{16->32}(n1))                   conv_flow.py:87-88
+ *   y  = GRN(g1)                                      conv_flow.py:22-45
+ *   o  = Conv1x1_{32->16}(y) * layer_scale + h2       conv_flow.py:95-115
+ * GRN needs sum_{hw} g1^2 per (row, channel) before it can be applied, so the
+ * chain runs twice (stats pass, apply pass) and never writes the 32-channel
+ * intermediates to HBM.  All "dot" arguments are the forward-mode tangents
+ * (SURVEY Appendix C); pass NULL for a primal-only call.  mfc_cnx_params /
+ * mfc_cnx_grads are HOST structs holding DEVICE pointers. */
+typedef struct {
+    const void* conv_w;      /* [3,3,16,16] dtype   conv_block/Conv_0/kernel */
+    const float* conv_b;     /* [16]                                        */
+    const void* exp_w;       /* [16,32] dtype       conv_block/Conv_1/kernel */
+    const float* exp_b;      /* [32]                                        */
+    const float* grn_gamma;  /* [32]  GlobalResponseNormalization_0/gamma   */
+    const float* grn_beta;   /* [32]                                        */
+    const void* con_w;       /* [32,16] dtype       conv_block/Conv_2/kernel */
+    const float* con_b;      /* [16]                                        */
+    const float* ls;         /* [16]  layer_scale_gamma                     */
+} mfc_cnx_params;
+
+/* fp32 gradient accumulators (+=) for the small parameters above */
+typedef struct {
+    float* conv_w; float* conv_b; float* exp_w; float* exp_b;
+    float* grn_gamma; float* grn_beta; float* con_w; float* con_b; float* ls;
+} mfc_cnx_grads;
+
+/* pass 1: S1[r,ch] += sum_hw g1^2 ; S2[r,ch] += sum_hw g1*g1dot (if h0dot).
+ * scale/shift (and their tangents) are fp32 [R,16]; S1/S2 fp32 [R,32] must be
+ * zeroed by the caller. */
+int mfc_cnx_stats(int dtype, int64_t R, int s, const void* h0, const void* h0dot,
+                  const float* scale, const float* shift, const float* scaledot, const float* shiftdot,
+                  const mfc_cnx_params* p, float* S1, float* S2, void* stream);
+
+/* GRN scalars from the statistics (conv_flow.py:32-37 and Appendix C):
+ * G = sqrt(S1); n = mean_ch G; q = G/(n+1e-6); qdot from S2 (NULL: skipped). */
+int mfc_grn_finalize(int64_t R, const float* S1, const float* S2, float* G, float* q, float* qdot,
+                     void* stream);
+
+/* pass 2: o (and odot) [R,s,s,16] dtype. */
+int mfc_cnx_apply(int dtype, int64_t R, int s, const void* h0, const void* h0dot,
+                  const float* scale, const float* shift, const float* scaledot, const float* shiftdot,
+                  const mfc_cnx_params* p, const float* q, const float* qdot,
+                  void* o, void* odot, void* stream);
+
+/* backward pass 1: dq[r,ch] += sum_hw dy*g1, dbeta[ch] += sum dy   (dq zeroed by caller) */
+int mfc_cnx_bwd_stats(int dtype, int64_t R, int s, const void* h0, const float* scale, const float* shift,
+                      const mfc_cnx_params* p, const float* q, const void* dout,
+                      float* dq, float* dbeta, void* stream);
+
+/* kG[r,ch] = (dL/dG)/G from dq (zero where G == 0); dgamma[ch] += sum_r dq */
+int mfc_grn_bwd_finalize(int64_t R, const float* G, const float* dq, float* kG, float* dgamma, void* stream);
+
+/* backward pass 2: dc1 [R,s,s,16] dtype (gradient at the 3x3 conv output) and the
+ * small-parameter gradients except conv_w/grn_gamma/grn_beta. */
+int mfc_cnx_bwd_main(int dtype, int64_t R, int s, const void* h0, const float* scale, const float* shift,
+                     const mfc_cnx_params* p, const float* q, const float* kG, const void* dout,
+                     void* dc1, const mfc_cnx_grads* g, void* stream);
+
+/* backward pass 3: dh0 = LN/FiLM-backward(conv3x3^T(dc1) + dout); conv_w
+ * gradient; dscale/dshift [R,16] fp32 (+=, zeroed by caller). */
+int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, const float* scale, const float* shift,
+                     const mfc_cnx_params* p, const void* dc1, const void* dout,
+                     void* dh0, const mfc_cnx_grads* g, float* dscale, float* dshift, void* stream);
+
+/* ------------------------------------------------------------------ */
+/* Loss-step element-wise kernels                                      */
+/* ------------------------------------------------------------------ */
+
+/* sinusoidal_embedding (meanflow_audio_codec/utils.py:5-13) of the model time
+ * input [t, h] (models/conv_flow.py:257-259, mlp_flow.py:181-183):
+ *   cond[r,:] = emb(t[r]) + emb(h[r]) (+ add[r,:] if add != NULL), fp32 [R,dim]
+ *   cond_dot  = tdot emb'(t) + hdot emb'(h)  (NULL tdot/hdot = 1; cond_dot NULL: skipped) */
+int mfc_time_embed(int64_t R, int dim, const float* t, const float* h, const float* tdot,
+                   const float* hdot, const float* add, float* cond, float* cond_dot, void* stream);
+
+/* sample_tr / logit_normal (meanflow_audio_codec/utils.py:32-45,
+ * trainers/time_sampling.py:39-135) from a Philox stream keyed (seed, step,
+ * GLOBAL row): t,r = sigmoid(N(mean,std)), t=max, r=min, global rows
+ * < int(Bglobal*data_proportion) get r = t.  pair=0: only t (logit-normal). */
+int mfc_sample_tr(uint64_t seed, uint64_t step, int64_t row0, int64_t B, int64_t Bglobal, float mean,
+                  float std, float data_proportion, int pair, float* t, float* r, void* stream);
+
+/* LinearNoiseSchedule (trainers/noise_schedules.py:52-88; noise_min=0, noise_max=1 gives the
+ * UniformNoiseSchedule :91-115):  z = (1-t) x + (nmin + nmax t) e  [dtype],
+ * target = nmax e - x [fp32].  e is drawn N(0,1) from Philox (seed, step, row0+b)
+ * when e_in == NULL (and written to e_out if given). */
+int mfc_flow_prepare(int dtype, int64_t B, int64_t D, const float* x, const float* e_in,
+                     const float* t, float noise_min, float noise_max, uint64_t seed, uint64_t step,
+                     int64_t row0, void* z, float* target, float* e_out, void* stream);
+
+/* N(0,1) fp32 [B,D] keyed (seed, stream_id, row0+b): sampler start noise
+ * (evaluators/sampling.py:50). */
+int mfc_randn(uint64_t seed, uint64_t stream_id, int64_t row0, int64_t B, int64_t D, float* out,
+              void* stream);
+
+/* tanh-GELU on [M,N]: rows < act_rows primal, rows >= act_rows tangents
+ * t*gelu'(pre[row-act_rows]); and its backward din = dout*gelu'(pre). */
+int mfc_gelu_fwd(int dtype, int64_t M, int64_t N, int64_t act_rows, const void* pre, void* out,
+                 void* stream);
+int mfc_gelu_bwd(int dtype, int64_t n, const void* pre, const void* dout, void* din, void* stream);
+
+/* Compound loss + gradient seed (trainers/loss_strategies.py:98-112,184-198,270-277;
+ * meanflow_audio_codec/utils.py:16-25).
+ *  kind 0: delta = u + (t-r) dudt - target        (iMF; FM with dudt == NULL)
+ *  kind 1: delta = u - (target - clip(t-r,0,1) dudt)   (MeanFlow)
+ *  only rows < n_tan carry a tangent (rows with r == t multiply it by 0).
+ *  mode 0: weighted L2  w=sg(1/(pe+c)^p), loss=mean(w pe); mode 1: MSE; mode 2: MeanFlow
+ *  adaptive weight on the per-example MEAN square, exponent p = 1-gamma.
+ * Means are over Bglobal (data-parallel shards pass their local B rows).
+ * Outputs: pe[B], seed[B] (dL/ddelta = seed*delta), loss (scalar, this shard's
+ * contribution), du [B,D] dtype (NULL: skipped). */
+int mfc_flow_loss(int dtype, int kind, int mode, int64_t B, int64_t Bglobal, int64_t D, const void* u,
+                  const void* dudt, int64_t n_tan, const float* t, const float* r,
+                  const float* target, float p, float c, float* pe, float* seed, float* loss,
+                  void* du, void* stream);
+
+/* out[N] (fp32) = (accumulate ? out : 0) + scale * sum_rows X[M,N]  -- bias gradients */
+int mfc_colsum(int dtype, int64_t M, int64_t N, const void* X, int64_t ld, float scale, float* out,
+               int accumulate, void* stream);
+
+/* out = a x + b y (y may be NULL) -- Heun update, evaluators/sampling.py:84 */
+int mfc_axpby(int dtype, int64_t n, float a, const void* x, float b, const void* y, void* out,
+              void* stream);
+int mfc_cast(int src_dtype, int dst_dtype, int64_t n, const void* x, void* out, void* stream);
+
+/* optax.adamw (trainers/train.py:236): m,v moments fp32, p fp32 master, optional
+ * bf16 working copy p_bf16, gradient in grad_dtype scaled by grad_scale.
+ * step is the 1-based update count (bias correction). */
+int mfc_adamw(int grad_dtype, int64_t n, float* p, void* p_bf16, const void* g, float grad_scale,
+              float* m, float* v, float lr, float b1, float b2, float eps, float wd, int64_t step,
+              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

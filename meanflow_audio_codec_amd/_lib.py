@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes
 import pathlib
 import re
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 import torch  # noqa: F401  (loads the ROCm runtime libmfc.so links against)
 
@@ -41,7 +41,35 @@ SIGNATURES = {
     "mfc_mdct_inv": (c_int, [_P, c_int64, c_int64, c_int, c_int, _P, c_int64, _P]),
     "mfc_gemm": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64,
                          _P, c_int64, c_int64, c_float, _P, c_int64, c_float, c_int, _P, _P]),
+    "mfc_cnx_stats": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_grn_finalize": (c_int, [c_int64, _P, _P, _P, _P, _P, _P]),
+    "mfc_cnx_apply": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_cnx_bwd_stats": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_grn_bwd_finalize": (c_int, [c_int64, _P, _P, _P, _P, _P]),
+    "mfc_cnx_bwd_main": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_cnx_bwd_conv": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_time_embed": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_sample_tr": (c_int, [c_uint64, c_uint64, c_int64, c_int64, c_int64, c_float, c_float, c_float, c_int,
+                              _P, _P, _P]),
+    "mfc_flow_prepare": (c_int, [c_int, c_int64, c_int64, _P, _P, _P, c_float, c_float, c_uint64, c_uint64,
+                                 c_int64, _P, _P, _P, _P]),
+    "mfc_randn": (c_int, [c_uint64, c_uint64, c_int64, c_int64, c_int64, _P, _P]),
+    "mfc_gelu_fwd": (c_int, [c_int, c_int64, c_int64, c_int64, _P, _P, _P]),
+    "mfc_gelu_bwd": (c_int, [c_int, c_int64, _P, _P, _P, _P]),
+    "mfc_flow_loss": (c_int, [c_int, c_int, c_int, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, _P,
+                              c_float, c_float, _P, _P, _P, _P, _P]),
+    "mfc_colsum": (c_int, [c_int, c_int64, c_int64, _P, c_int64, c_float, _P, c_int, _P]),
+    "mfc_axpby": (c_int, [c_int, c_int64, c_float, _P, c_float, _P, _P, _P]),
+    "mfc_cast": (c_int, [c_int, c_int, c_int64, _P, _P, _P]),
+    "mfc_adamw": (c_int, [c_int, c_int64, _P, _P, _P, c_float, _P, _P, c_float, c_float, c_float, c_float,
+                          c_float, c_int64, _P]),
 }
+
+
+class CnxParams(ctypes.Structure):
+    """mfc_cnx_params / mfc_cnx_grads (9 device pointers)."""
+    _fields_ = [(n, c_void_p) for n in ("conv_w", "conv_b", "exp_w", "exp_b", "grn_gamma", "grn_beta",
+                                         "con_w", "con_b", "ls")]
 
 
 def header_symbols() -> list[str]:

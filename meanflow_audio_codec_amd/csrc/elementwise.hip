@@ -1,0 +1,450 @@
+// Element-wise / reduction kernels of the loss step (HBM-bound, vectorised):
+// time embedding (+tangent), noise + (t, r) sampling (Philox), interpolation
+// and target, GELU (+tangent rows, +backward), the compound iMF / MF / FM
+// loss with its gradient seed, column sums for bias gradients, axpby and the
+// fused AdamW update.
+#include "mfc_common.h"
+
+namespace {
+
+constexpr int ET = 256;
+
+inline unsigned grid_for(int64_t n, int per_thread = 1) {
+    int64_t b = ceil_div64(n, (int64_t)ET * per_thread);
+    if (b > 16384) b = 16384;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// ---- Philox4x32-10 ---------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+__device__ inline U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        U4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+__device__ inline float u01(uint32_t u) { return ((float)(u >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+__device__ inline void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float r = sqrtf(-2.0f * logf(u01(a)));
+    float s, c;
+    sincospif(2.0f * u01(b), &s, &c);
+    n0 = r * c;
+    n1 = r * s;
+}
+// 4 standard normals for (stream, row, quad index)
+__device__ inline void normal4(uint64_t seed, uint32_t stream, uint64_t row, uint32_t quad, float out[4]) {
+    U4 c{quad, (uint32_t)row, (uint32_t)(row >> 32), stream};
+    const U4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    box_muller(r.x, r.y, out[0], out[1]);
+    box_muller(r.z, r.w, out[2], out[3]);
+}
+
+// ---- sinusoidal time embedding (meanflow_audio_codec/utils.py:5-13) ---------
+// cond[r] = emb(t[r]) + emb(h[r]) (+ add[r]); cdot[r] = tdot emb'(t) + hdot emb'(h)
+__global__ void time_embed_kernel(int64_t R, int dim, const float* t, const float* h, const float* tdot,
+                                  const float* hdot, const float* add, float* cond, float* cdot) {
+    const int half = dim / 2;
+    const int64_t total = R * dim;
+    for (int64_t o = blockIdx.x * (int64_t)ET + threadIdx.x; o < total; o += (int64_t)gridDim.x * ET) {
+        const int64_t r = o / dim;
+        const int c = (int)(o - r * dim);
+        const int j = c < half ? c : c - half;
+        const float f = expf(-logf(10000.0f) * (float)j / (float)half);
+        const float at = t[r] * f, ah = h[r] * f;
+        float v, dv = 0.f;
+        if (c < half) {
+            v = cosf(at) + cosf(ah);
+            if (cdot) dv = -(tdot ? tdot[r] : 1.0f) * f * sinf(at) - (hdot ? hdot[r] : 1.0f) * f * sinf(ah);
+        } else {
+            v = sinf(at) + sinf(ah);
+            if (cdot) dv = (tdot ? tdot[r] : 1.0f) * f * cosf(at) + (hdot ? hdot[r] : 1.0f) * f * cosf(ah);
+        }
+        if (add) v += add[o];
+        cond[o] = v;
+        if (cdot) cdot[o] = dv;
+    }
+}
+
+// ---- (t, r) sampling: meanflow_audio_codec/utils.py:32-45 --------------------
+// t,r = sigmoid(N(mean,std)); t=max, r=min; GLOBAL rows < int(Bglobal*prop): r = t.
+__global__ void sample_tr_kernel(uint64_t seed, uint64_t step, int64_t row0, int64_t B, int64_t Bglobal,
+                                 float mean, float stdv, float prop, int pair, float* t, float* r) {
+    const int64_t i = blockIdx.x * (int64_t)ET + threadIdx.x;
+    if (i >= B) return;
+    float n[4];
+    normal4(seed, 0x7472u, (uint64_t)(row0 + i), (uint32_t)step, n);
+    float a = 1.0f / (1.0f + expf(-(n[0] * stdv + mean)));
+    if (!pair) { t[i] = a; return; }
+    float b = 1.0f / (1.0f + expf(-(n[1] * stdv + mean)));
+    const float tt = fmaxf(a, b), rr = fminf(a, b);
+    const int64_t data_size = (int64_t)((double)Bglobal * (double)prop);
+    t[i] = tt;
+    r[i] = (row0 + i) < data_size ? tt : rr;
+}
+
+// ---- noise + interpolation + target -----------------------------------------
+// z = (1-t) x + (nmin + nmax t) e ; target = nmax e - x   (noise_schedules.py:69-88)
+// e is drawn from Philox (seed, step, global row) when e_in == nullptr.
+template <typename T>
+__global__ void flow_prepare_kernel(int64_t B, int64_t D, const float* x, const float* e_in, const float* t,
+                                    float nmin, float nmax, uint64_t seed, uint64_t step, int64_t row0,
+                                    T* z, float* target, float* e_out) {
+    const int64_t quads = (D + 3) / 4;
+    const int64_t total = B * quads;
+    for (int64_t o = blockIdx.x * (int64_t)ET + threadIdx.x; o < total; o += (int64_t)gridDim.x * ET) {
+        const int64_t b = o / quads;
+        const int64_t qd = o - b * quads;
+        float e4[4];
+        if (e_in) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e4[i] = (4 * qd + i < D) ? e_in[b * D + 4 * qd + i] : 0.f;
+        } else {
+            normal4(seed ^ (step * 0x9E3779B97F4A7C15ull), 0x6e6fu, (uint64_t)(row0 + b), (uint32_t)qd, e4);
+        }
+        const float tt = t[b];
+        const float a = 1.0f - tt, c = nmin + nmax * tt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t d = 4 * qd + i;
+            if (d < D) {
+                const float xv = x[b * D + d];
+                St<T>::st(z + b * D + d, a * xv + c * e4[i]);
+                target[b * D + d] = nmax * e4[i] - xv;
+                if (e_out) e_out[b * D + d] = e4[i];
+            }
+        }
+    }
+}
+
+__global__ void randn_kernel(uint64_t seed, uint64_t stream, int64_t row0, int64_t B, int64_t D, float* out) {
+    const int64_t quads = (D + 3) / 4;
+    const int64_t total = B * quads;
+    for (int64_t o = blockIdx.x * (int64_t)ET + threadIdx.x; o < total; o += (int64_t)gridDim.x * ET) {
+        const int64_t b = o / quads, qd = o - b * quads;
+        float e4[4];
+        normal4(seed, (uint32_t)stream, (uint64_t)(row0 + b), (uint32_t)qd, e4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * qd + i < D) out[b * D + 4 * qd + i] = e4[i];
+    }
+}
+
+// ---- GELU on [M,N] with tangent rows / backward ------------------------------
+template <typename T>
+__global__ void gelu_fwd_kernel(int64_t M, int64_t N, int64_t act_rows, const T* pre, T* out) {
+    const int64_t total = M * N;
+    for (int64_t o = blockIdx.x * (int64_t)ET + threadIdx.x; o < total; o += (int64_t)gridDim.x * ET) {
+        const int64_t row = o / N;
+        const float v = St<T>::ld(pre + o);
+        float y;
+        if (row < act_rows) y = gelu_f(v);
+        else y = v * gelu_grad_f(St<T>::ld(pre + o - act_rows * N));
+        St<T>::st(out + o, y);
+    }
+}
+template <typename T>
+__global__ void gelu_bwd_kernel(int64_t n, const T* pre, const T* dout, T* din) {
+    for (int64_t o = blockIdx.x * (int64_t)ET + threadIdx.x; o < n; o += (int64_t)gridDim.x * ET)
+        St<T>::st(din + o, St<T>::ld(dout + o) * gelu_grad_f(St<T>::ld(pre + o)));
+}
+
+// ---- loss ---------------------------------------------------------------------
+// kind 0 (iMF / FM): delta = u + coef*dudt - target, coef = (t - r)      loss_strategies.py:270
+// kind 1 (MF):       delta = u - (target - clip(t-r,0,1) dudt)           loss_strategies.py:184-188
+// pe[b] = sum_d delta^2
+template <typename T>
+__global__ void loss_pe_kernel(int kind, int64_t B, int64_t D, const T* u, const T* dudt, int64_t n_tan,
+                               const float* t, const float* r, const float* target, float* pe) {
+    __shared__ float red[ET / 64];
+    const int64_t b = blockIdx.y;
+    float coef = 0.f;
+    if (dudt && b < n_tan) {
+        coef = t[b] - r[b];
+        if (kind == 1) coef = fminf(fmaxf(coef, 0.f), 1.f);
+    }
+    float acc = 0.f;
+    for (int64_t d = blockIdx.x * (int64_t)ET + threadIdx.x; d < D; d += (int64_t)gridDim.x * ET) {
+        float v = St<T>::ld(u + b * D + d) - target[b * D + d];
+        if (coef != 0.f) v += coef * St<T>::ld(dudt + b * D + d);
+        acc += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < ET / 64; ++i) s += red[i];
+        atomicAdd(pe + b, s);
+    }
+}
+
+// per-example weights and the scalar loss:
+//  mode 0: weighted_l2_loss (utils.py:16-25)   w = 1/(pe + c)^p, loss = mean_b(w pe),   seed = 2 w / Bg
+//  mode 1: plain MSE                           loss = sum pe / (Bg D),                  seed = 2 / (Bg D)
+//  mode 2: MeanFlow adaptive (loss_strategies.py:190-196) dsq = pe/D, w = 1/(dsq+c)^(1-gamma),
+//          loss = mean_b(w dsq), seed = 2 w / (Bg D)
+__global__ void loss_finalize_kernel(int mode, int64_t B, int64_t Bglobal, int64_t D, const float* pe, float p,
+                                     float c, float* seed, float* loss) {
+    float acc = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+        const float v = pe[b];
+        float w, l;
+        if (mode == 0) { w = 1.0f / powf(v + c, p); l = w * v / (float)Bglobal; seed[b] = 2.0f * w / (float)Bglobal; }
+        else if (mode == 1) { l = v / ((float)Bglobal * (float)D); seed[b] = 2.0f / ((float)Bglobal * (float)D); }
+        else {
+            const float dsq = v / (float)D;
+            w = 1.0f / powf(dsq + c, p);
+            l = w * dsq / (float)Bglobal;
+            seed[b] = 2.0f * w / ((float)Bglobal * (float)D);
+        }
+        acc += l;
+    }
+    __shared__ float red[16];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < (int)(blockDim.x / 64); ++i) s += red[i];
+        *loss = s;
+    }
+}
+
+// du[b,d] = seed[b] * delta[b,d]
+template <typename T>
+__global__ void loss_grad_kernel(int kind, int64_t B, int64_t D, const T* u, const T* dudt, int64_t n_tan,
+                                 const float* t, const float* r, const float* target, const float* seed, T* du) {
+    const int64_t total = B * D;
+    for (int64_t o = blockIdx.x * (int64_t)ET + threadIdx.x; o < total; o += (int64_t)gridDim.x * ET) {
+        const int64_t b = o / D;
+        float v = St<T>::ld(u + o) - target[o];
+        if (dudt && b < n_tan) {
+            float coef = t[b] - r[b];
+            if (kind == 1) coef = fminf(fmaxf(coef, 0.f), 1.f);
+            v += coef * St<T>::ld(dudt + o);
+        }
+        St<T>::st(du + o, seed[b] * v);
+    }
+}
+
+// ---- column sums (bias gradients) ----------------------------------------------
+template <typename T>
+__global__ void colsum_kernel(int64_t M, int64_t N, const T* X, int64_t ld, float scale, float* out, int accum) {
+    for (int64_t c = blockIdx.x * (int64_t)ET + threadIdx.x; c < N; c += (int64_t)gridDim.x * ET) {
+        float acc = 0.f;
+        for (int64_t m = 0; m < M; ++m) acc += St<T>::ld(X + m * ld + c);
+        acc *= scale;
+        out[c] = accum ? out[c] + acc : acc;
+    }
+}
+
+template <typename T>
+__global__ void axpby_kernel(int64_t n, float a, const T* x, float b, const T* y, T* out) {
+    for (int64_t o = blockIdx.x * (int64_t)ET + threadIdx.x; o < n; o += (int64_t)gridDim.x * ET) {
+        float v = a * St<T>::ld(x + o);
+        if (y) v += b * St<T>::ld(y + o);
+        St<T>::st(out + o, v);
+    }
+}
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(int64_t n, const TI* x, TO* out) {
+    for (int64_t o = blockIdx.x * (int64_t)ET + threadIdx.x; o < n; o += (int64_t)gridDim.x * ET)
+        St<TO>::st(out + o, St<TI>::ld(x + o));
+}
+
+// ---- AdamW (optax.adamw, trainers/train.py:236) ----------------
+// m <- b1 m + (1-b1) g; v <- b2 v + (1-b2) g^2;
+// p <- p - lr (mhat / (sqrt(vhat) + eps) + wd p); optional bf16 working copy.
+template <typename TG>
+__global__ void adamw_kernel(int64_t n, float* p, u16* pw, const TG* g, float gscale, float* m, float* v,
+                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
+    for (int64_t o = blockIdx.x * (int64_t)ET + threadIdx.x; o < n; o += (int64_t)gridDim.x * ET) {
+        const float gv = St<TG>::ld(g + o) * gscale;
+        const float mm = b1 * m[o] + (1.0f - b1) * gv;
+        const float vv = b2 * v[o] + (1.0f - b2) * gv * gv;
+        m[o] = mm;
+        v[o] = vv;
+        const float pv = p[o];
+        const float upd = (mm / bc1) / (sqrtf(vv / bc2) + eps) + wd * pv;
+        const float np = pv - lr * upd;
+        p[o] = np;
+        if (pw) pw[o] = f32_to_bf16(np);
+    }
+}
+
+}  // namespace
+
+#define DT_OK(dt) ((dt) == MFC_F32 || (dt) == MFC_BF16)
+
+extern "C" int mfc_time_embed(int64_t R, int dim, const float* t, const float* h, const float* tdot,
+                              const float* hdot, const float* add, float* cond, float* cond_dot, void* stream) {
+    if (!t || !h || !cond) return MFC_EFAULT;
+    if (R <= 0 || dim <= 0 || (dim & 1)) return MFC_EINVAL;
+    hipLaunchKernelGGL(time_embed_kernel, dim3(grid_for(R * dim)), dim3(ET), 0, (hipStream_t)stream, R, dim, t, h,
+                       tdot, hdot, add, cond, cond_dot);
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_sample_tr(uint64_t seed, uint64_t step, int64_t row0, int64_t B, int64_t Bglobal, float mean,
+                             float std, float data_proportion, int pair, float* t, float* r, void* stream) {
+    if (!t || (pair && !r)) return MFC_EFAULT;
+    if (B <= 0 || Bglobal < B || row0 < 0) return MFC_EINVAL;
+    hipLaunchKernelGGL(sample_tr_kernel, dim3(grid_for(B)), dim3(ET), 0, (hipStream_t)stream, seed, step, row0, B,
+                       Bglobal, mean, std, data_proportion, pair, t, r);
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_flow_prepare(int dtype, int64_t B, int64_t D, const float* x, const float* e_in,
+                                const float* t, float noise_min, float noise_max, uint64_t seed, uint64_t step,
+                                int64_t row0, void* z, float* target, float* e_out, void* stream) {
+    if (!x || !t || !z || !target) return MFC_EFAULT;
+    if (B <= 0 || D <= 0 || !DT_OK(dtype)) return MFC_EINVAL;
+    const unsigned grid = grid_for(B * ((D + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_F32)
+        hipLaunchKernelGGL(flow_prepare_kernel<float>, dim3(grid), dim3(ET), 0, st, B, D, x, e_in, t, noise_min,
+                           noise_max, seed, step, row0, (float*)z, target, e_out);
+    else
+        hipLaunchKernelGGL(flow_prepare_kernel<u16>, dim3(grid), dim3(ET), 0, st, B, D, x, e_in, t, noise_min,
+                           noise_max, seed, step, row0, (u16*)z, target, e_out);
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_randn(uint64_t seed, uint64_t stream_id, int64_t row0, int64_t B, int64_t D, float* out,
+                         void* stream) {
+    if (!out) return MFC_EFAULT;
+    if (B <= 0 || D <= 0) return MFC_EINVAL;
+    hipLaunchKernelGGL(randn_kernel, dim3(grid_for(B * ((D + 3) / 4))), dim3(ET), 0, (hipStream_t)stream, seed,
+                       stream_id, row0, B, D, out);
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_gelu_fwd(int dtype, int64_t M, int64_t N, int64_t act_rows, const void* pre, void* out,
+                            void* stream) {
+    if (!pre || !out) return MFC_EFAULT;
+    if (M <= 0 || N <= 0 || act_rows <= 0 || act_rows > M || M > 2 * act_rows || !DT_OK(dtype)) return MFC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_F32)
+        hipLaunchKernelGGL(gelu_fwd_kernel<float>, dim3(grid_for(M * N)), dim3(ET), 0, st, M, N, act_rows,
+                           (const float*)pre, (float*)out);
+    else
+        hipLaunchKernelGGL(gelu_fwd_kernel<u16>, dim3(grid_for(M * N)), dim3(ET), 0, st, M, N, act_rows,
+                           (const u16*)pre, (u16*)out);
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_gelu_bwd(int dtype, int64_t n, const void* pre, const void* dout, void* din, void* stream) {
+    if (!pre || !dout || !din) return MFC_EFAULT;
+    if (n <= 0 || !DT_OK(dtype)) return MFC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_F32)
+        hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(grid_for(n)), dim3(ET), 0, st, n, (const float*)pre,
+                           (const float*)dout, (float*)din);
+    else
+        hipLaunchKernelGGL(gelu_bwd_kernel<u16>, dim3(grid_for(n)), dim3(ET), 0, st, n, (const u16*)pre,
+                           (const u16*)dout, (u16*)din);
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_flow_loss(int dtype, int kind, int mode, int64_t B, int64_t Bglobal, int64_t D, const void* u,
+                             const void* dudt, int64_t n_tan, const float* t, const float* r,
+                             const float* target, float p, float c, float* pe, float* seed, float* loss,
+                             void* du, void* stream) {
+    if (!u || !target || !pe || !seed || !loss) return MFC_EFAULT;
+    if (dudt && (!t || !r)) return MFC_EFAULT;
+    if (B <= 0 || D <= 0 || Bglobal < B || n_tan < 0 || n_tan > B || !DT_OK(dtype)) return MFC_EINVAL;
+    if (kind < 0 || kind > 1 || mode < 0 || mode > 2 || B > 65535) return MFC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(pe, 0, B * sizeof(float), st) != hipSuccess) return MFC_EHIP;
+    int64_t gx = ceil_div64(D, ET * 8);
+    if (gx > 256) gx = 256;
+    dim3 g1((unsigned)gx, (unsigned)B);
+    if (dtype == MFC_F32)
+        hipLaunchKernelGGL(loss_pe_kernel<float>, g1, dim3(ET), 0, st, kind, B, D, (const float*)u,
+                           (const float*)dudt, n_tan, t, r, target, pe);
+    else
+        hipLaunchKernelGGL(loss_pe_kernel<u16>, g1, dim3(ET), 0, st, kind, B, D, (const u16*)u, (const u16*)dudt,
+                           n_tan, t, r, target, pe);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, mode, B, Bglobal, D, pe, p, c, seed, loss);
+    if (du) {
+        if (dtype == MFC_F32)
+            hipLaunchKernelGGL(loss_grad_kernel<float>, dim3(grid_for(B * D)), dim3(ET), 0, st, kind, B, D,
+                               (const float*)u, (const float*)dudt, n_tan, t, r, target, seed, (float*)du);
+        else
+            hipLaunchKernelGGL(loss_grad_kernel<u16>, dim3(grid_for(B * D)), dim3(ET), 0, st, kind, B, D,
+                               (const u16*)u, (const u16*)dudt, n_tan, t, r, target, seed, (u16*)du);
+    }
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_colsum(int dtype, int64_t M, int64_t N, const void* X, int64_t ld, float scale, float* out,
+                          int accumulate, void* stream) {
+    if (!X || !out) return MFC_EFAULT;
+    if (M <= 0 || N <= 0 || ld < N || !DT_OK(dtype)) return MFC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3(grid_for(N)), dim3(ET), 0, st, M, N, (const float*)X, ld,
+                           scale, out, accumulate);
+    else
+        hipLaunchKernelGGL(colsum_kernel<u16>, dim3(grid_for(N)), dim3(ET), 0, st, M, N, (const u16*)X, ld, scale,
+                           out, accumulate);
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_axpby(int dtype, int64_t n, float a, const void* x, float b, const void* y, void* out,
+                         void* stream) {
+    if (!x || !out) return MFC_EFAULT;
+    if (n <= 0 || !DT_OK(dtype)) return MFC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_F32)
+        hipLaunchKernelGGL(axpby_kernel<float>, dim3(grid_for(n)), dim3(ET), 0, st, n, a, (const float*)x, b,
+                           (const float*)y, (float*)out);
+    else
+        hipLaunchKernelGGL(axpby_kernel<u16>, dim3(grid_for(n)), dim3(ET), 0, st, n, a, (const u16*)x, b,
+                           (const u16*)y, (u16*)out);
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_cast(int src_dtype, int dst_dtype, int64_t n, const void* x, void* out, void* stream) {
+    if (!x || !out) return MFC_EFAULT;
+    if (n <= 0 || !DT_OK(src_dtype) || !DT_OK(dst_dtype)) return MFC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned g = grid_for(n);
+    if (src_dtype == MFC_F32 && dst_dtype == MFC_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, u16>), dim3(g), dim3(ET), 0, st, n, (const float*)x, (u16*)out);
+    else if (src_dtype == MFC_BF16 && dst_dtype == MFC_F32)
+        hipLaunchKernelGGL((cast_kernel<u16, float>), dim3(g), dim3(ET), 0, st, n, (const u16*)x, (float*)out);
+    else if (src_dtype == MFC_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(ET), 0, st, n, (const float*)x, (float*)out);
+    else
+        hipLaunchKernelGGL((cast_kernel<u16, u16>), dim3(g), dim3(ET), 0, st, n, (const u16*)x, (u16*)out);
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_adamw(int grad_dtype, int64_t n, float* p, void* p_bf16, const void* g, float grad_scale,
+                         float* m, float* v, float lr, float b1, float b2, float eps, float wd, int64_t step,
+                         void* stream) {
+    if (!p || !g || !m || !v) return MFC_EFAULT;
+    if (n <= 0 || step < 1 || !DT_OK(grad_dtype)) return MFC_EINVAL;
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+    hipStream_t st = (hipStream_t)stream;
+    if (grad_dtype == MFC_F32)
+        hipLaunchKernelGGL(adamw_kernel<float>, dim3(grid_for(n)), dim3(ET), 0, st, n, p, (u16*)p_bf16,
+                           (const float*)g, grad_scale, m, v, lr, b1, b2, eps, wd, bc1, bc2);
+    else
+        hipLaunchKernelGGL(adamw_kernel<u16>, dim3(grid_for(n)), dim3(ET), 0, st, n, p, (u16*)p_bf16,
+                           (const u16*)g, grad_scale, m, v, lr, b1, b2, eps, wd, bc1, bc2);
+    return mfc_launch_status();
+}

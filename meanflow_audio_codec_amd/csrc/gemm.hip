@@ -22,20 +22,6 @@ constexpr int BM = 128, BN = 128, BK = 32, GT = 256;
 constexpr int LDS_PAD = 4;
 constexpr int LDK = BK + LDS_PAD;  // elements per LDS row
 
-template <typename T> struct Frag;
-template <> struct Frag<float> { typedef f32x4 type; };
-template <> struct Frag<u16> { typedef s16x4 type; };
-
-__device__ inline void mma16(f32x4& acc, const f32x4& a, const f32x4& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
-}
-__device__ inline void mma16(f32x4& acc, const s16x4& a, const s16x4& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0);
-}
-
 struct GemmArgs {
     int64_t M, N, K;
     const void* A; int64_t lda;

@@ -57,6 +57,29 @@ __device__ inline float gelu_grad_f(float x) {
 // second derivative, needed for d/dx of (t * gelu'(x)) in the tangent's backward
 // (not on the iMF path: the tangent carries no gradient) -- kept out.
 
+// ---- MFMA 16x16 "K16 step": D += A[16 x 16k] * B[16k x 16] ----------------
+// Lane l = 16*q + r.  A fragment: 4 consecutive k (4q..4q+3) of row r;
+// B fragment: the same 4 k of column r.  fp32 storage issues four
+// v_mfma_f32_16x16x4_f32 (exact fp32 fma chain), bf16 storage one
+// v_mfma_f32_16x16x16_bf16.  C/D: col = l&15, row = 4*(l>>4) + reg.
+template <typename T> struct Frag;
+template <> struct Frag<float> { typedef f32x4 type; };
+template <> struct Frag<u16> { typedef s16x4 type; };
+
+__device__ inline void mma16(f32x4& acc, const f32x4& a, const f32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+}
+__device__ inline void mma16(f32x4& acc, const s16x4& a, const s16x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0);
+}
+__device__ inline void make_frag(f32x4& f, float a, float b, float c, float d) { f = f32x4{a, b, c, d}; }
+__device__ inline void make_frag(s16x4& f, float a, float b, float c, float d) {
+    f = s16x4{(short)f32_to_bf16(a), (short)f32_to_bf16(b), (short)f32_to_bf16(c), (short)f32_to_bf16(d)};
+}
+
 static inline int mfc_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MFC_OK : MFC_EHIP;

@@ -43,3 +43,232 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a=False, trans_b=False, bias
         int(splitk), _lib.ptr(ws), _lib.stream_ptr())
     _lib.check(rc, "mfc_gemm")
     return out
+
+
+# ---------------------------------------------------------------------------
+# ConvNeXt block interior
+# ---------------------------------------------------------------------------
+import ctypes  # noqa: E402
+
+_CNX_FIELDS = ("conv_w", "conv_b", "exp_w", "exp_b", "grn_gamma", "grn_beta", "con_w", "con_b", "ls")
+
+
+def _cnx_struct(tensors: dict) -> _lib.CnxParams:
+    s = _lib.CnxParams()
+    for f in _CNX_FIELDS:
+        t = tensors.get(f)
+        setattr(s, f, None if t is None else t.data_ptr())
+    return s
+
+
+def cnx_check_weights(w: dict, dtype) -> None:
+    shapes = {"conv_w": (3, 3, 16, 16), "conv_b": (16,), "exp_w": (16, 32), "exp_b": (32,),
+              "grn_gamma": (32,), "grn_beta": (32,), "con_w": (32, 16), "con_b": (16,), "ls": (16,)}
+    for k, shp in shapes.items():
+        t = w[k]
+        want = dtype if k.endswith("_w") else torch.float32
+        if tuple(t.shape)[-len(shp):] != shp and t.numel() != int(torch.tensor(shp).prod()):
+            raise _lib.MfcError(f"ConvNeXt weight {k}: shape {tuple(t.shape)} != {shp} "
+                                "(only C = 16 channels is implemented: condition_dimension >= 64)")
+        if t.dtype != want or not t.is_contiguous() or not t.is_cuda:
+            raise _lib.MfcError(f"ConvNeXt weight {k}: need contiguous device {want}, got {t.dtype}")
+
+
+def _film(x, R):
+    assert x.dtype == torch.float32 and x.shape == (R, 16) and x.is_contiguous()
+    return x
+
+
+def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, shiftdot=None, out=None,
+                outdot=None):
+    """o = ConvNeXtBlock(FiLM(LN(h0))) on [R, s, s, 16]; returns (o, odot, G, q).
+    Runs mfc_cnx_stats -> mfc_grn_finalize -> mfc_cnx_apply."""
+    _lib.require_cuda(h0)
+    R = h0.shape[0]
+    dt = _lib.dtype_code(h0.dtype)
+    assert h0.is_contiguous() and h0.numel() == R * s * s * 16
+    cnx_check_weights(w, h0.dtype)
+    _film(scale, R), _film(shift, R)
+    jvp = h0dot is not None
+    if jvp:
+        assert h0dot.is_contiguous() and h0dot.shape == h0.shape and h0dot.dtype == h0.dtype
+        _film(scaledot, R), _film(shiftdot, R)
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    ps = _cnx_struct(w)
+    dev = h0.device
+    S = torch.zeros((2 if jvp else 1, R, 32), dtype=torch.float32, device=dev)
+    G = torch.empty((R, 32), dtype=torch.float32, device=dev)
+    q = torch.empty_like(G)
+    qd = torch.empty_like(G) if jvp else None
+    _lib.check(L.mfc_cnx_stats(dt, R, s, h0.data_ptr(), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
+                               _lib.ptr(scaledot), _lib.ptr(shiftdot), ctypes.byref(ps), S[0].data_ptr(),
+                               S[1].data_ptr() if jvp else None, st), "mfc_cnx_stats")
+    _lib.check(L.mfc_grn_finalize(R, S[0].data_ptr(), S[1].data_ptr() if jvp else None, G.data_ptr(),
+                                  q.data_ptr(), _lib.ptr(qd), st), "mfc_grn_finalize")
+    o = out if out is not None else torch.empty_like(h0)
+    od = (outdot if outdot is not None else torch.empty_like(h0)) if jvp else None
+    _lib.check(L.mfc_cnx_apply(dt, R, s, h0.data_ptr(), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
+                               _lib.ptr(scaledot), _lib.ptr(shiftdot), ctypes.byref(ps), q.data_ptr(),
+                               _lib.ptr(qd), o.data_ptr(), _lib.ptr(od), st), "mfc_cnx_apply")
+    return o, od, G, q
+
+
+def cnx_backward(h0, scale, shift, w: dict, s: int, G, q, dout, grads: dict, dh0=None, scratch=None):
+    """Backward of cnx_forward's primal: returns (dh0, dscale, dshift); accumulates (+=) the
+    small-parameter gradients into the fp32 tensors of ``grads`` (same keys as ``w``)."""
+    _lib.require_cuda(h0, dout)
+    R = h0.shape[0]
+    dt = _lib.dtype_code(h0.dtype)
+    assert dout.is_contiguous() and dout.shape == h0.shape and dout.dtype == h0.dtype
+    for k in _CNX_FIELDS:
+        g = grads[k]
+        assert g.dtype == torch.float32 and g.is_contiguous() and g.numel() == w[k].numel(), k
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    ps, gs = _cnx_struct(w), _cnx_struct(grads)
+    dev = h0.device
+    dq = torch.zeros((R, 32), dtype=torch.float32, device=dev)
+    kG = torch.empty_like(dq)
+    _lib.check(L.mfc_cnx_bwd_stats(dt, R, s, h0.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctypes.byref(ps),
+                                   q.data_ptr(), dout.data_ptr(), dq.data_ptr(), grads["grn_beta"].data_ptr(), st),
+               "mfc_cnx_bwd_stats")
+    _lib.check(L.mfc_grn_bwd_finalize(R, G.data_ptr(), dq.data_ptr(), kG.data_ptr(),
+                                      grads["grn_gamma"].data_ptr(), st), "mfc_grn_bwd_finalize")
+    dc1 = scratch if scratch is not None else torch.empty_like(h0)
+    _lib.check(L.mfc_cnx_bwd_main(dt, R, s, h0.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctypes.byref(ps),
+                                  q.data_ptr(), kG.data_ptr(), dout.data_ptr(), dc1.data_ptr(), ctypes.byref(gs),
+                                  st), "mfc_cnx_bwd_main")
+    if dh0 is None:
+        dh0 = torch.empty_like(h0)
+    dsc = torch.zeros((R, 16), dtype=torch.float32, device=dev)
+    dsh = torch.zeros_like(dsc)
+    _lib.check(L.mfc_cnx_bwd_conv(dt, R, s, h0.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctypes.byref(ps),
+                                  dc1.data_ptr(), dout.data_ptr(), dh0.data_ptr(), ctypes.byref(gs),
+                                  dsc.data_ptr(), dsh.data_ptr(), st), "mfc_cnx_bwd_conv")
+    return dh0, dsc, dsh
+
+
+# ---------------------------------------------------------------------------
+# element-wise
+# ---------------------------------------------------------------------------
+
+
+def time_embed(t, h, dim, add=None, want_dot=False, tdot=None, hdot=None):
+    _lib.require_cuda(t, h)
+    R = t.numel()
+    assert t.dtype == torch.float32 and h.dtype == torch.float32 and h.numel() == R
+    cond = torch.empty((R, dim), dtype=torch.float32, device=t.device)
+    cdot = torch.empty_like(cond) if want_dot else None
+    if add is not None:
+        assert add.shape == (R, dim) and add.dtype == torch.float32 and add.is_contiguous()
+    _lib.check(_lib.lib().mfc_time_embed(R, dim, t.data_ptr(), h.data_ptr(), _lib.ptr(tdot), _lib.ptr(hdot),
+                                         _lib.ptr(add), cond.data_ptr(), _lib.ptr(cdot), _lib.stream_ptr()),
+               "mfc_time_embed")
+    return cond, cdot
+
+
+def gelu_fwd(pre, act_rows=None):
+    M, N = pre.shape
+    out = torch.empty_like(pre)
+    _lib.check(_lib.lib().mfc_gelu_fwd(_lib.dtype_code(pre.dtype), M, N, M if act_rows is None else act_rows,
+                                       pre.data_ptr(), out.data_ptr(), _lib.stream_ptr()), "mfc_gelu_fwd")
+    return out
+
+
+def gelu_bwd(pre, dout):
+    assert pre.shape == dout.shape and pre.is_contiguous() and dout.is_contiguous()
+    din = torch.empty_like(dout)
+    _lib.check(_lib.lib().mfc_gelu_bwd(_lib.dtype_code(pre.dtype), pre.numel(), pre.data_ptr(), dout.data_ptr(),
+                                       din.data_ptr(), _lib.stream_ptr()), "mfc_gelu_bwd")
+    return din
+
+
+def colsum(X, scale=1.0, out=None, accumulate=False):
+    M, N = X.shape
+    assert X.stride(1) == 1
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=X.device)
+    _lib.check(_lib.lib().mfc_colsum(_lib.dtype_code(X.dtype), M, N, X.data_ptr(), X.stride(0), float(scale),
+                                     out.data_ptr(), int(accumulate), _lib.stream_ptr()), "mfc_colsum")
+    return out
+
+
+def axpby(a, x, b=0.0, y=None, out=None):
+    assert x.is_contiguous() and (y is None or (y.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype))
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.lib().mfc_axpby(_lib.dtype_code(x.dtype), x.numel(), float(a), x.data_ptr(), float(b),
+                                    _lib.ptr(y), out.data_ptr(), _lib.stream_ptr()), "mfc_axpby")
+    return out
+
+
+def cast(x, dtype, out=None):
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _lib.check(_lib.lib().mfc_cast(_lib.dtype_code(x.dtype), _lib.dtype_code(dtype), x.numel(), x.data_ptr(),
+                                   out.data_ptr(), _lib.stream_ptr()), "mfc_cast")
+    return out
+
+
+def randn(seed, stream_id, row0, B, D, device="cuda"):
+    out = torch.empty((B, D), dtype=torch.float32, device=device)
+    _lib.check(_lib.lib().mfc_randn(seed, stream_id, row0, B, D, out.data_ptr(), _lib.stream_ptr()), "mfc_randn")
+    return out
+
+
+def sample_tr(seed, step, row0, B, Bglobal, mean, std, data_proportion, pair=True, device="cuda"):
+    t = torch.empty((B, 1), dtype=torch.float32, device=device)
+    r = torch.empty((B, 1), dtype=torch.float32, device=device) if pair else None
+    _lib.check(_lib.lib().mfc_sample_tr(seed, step, row0, B, Bglobal, float(mean), float(std),
+                                        float(data_proportion), int(pair), t.data_ptr(), _lib.ptr(r),
+                                        _lib.stream_ptr()), "mfc_sample_tr")
+    return t, r
+
+
+def flow_prepare(x, t, dtype, noise_min, noise_max, e=None, seed=0, step=0, row0=0, want_e=False):
+    """z [dtype], target [fp32] (and e if drawn here and want_e)."""
+    B, D = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and t.numel() == B and t.dtype == torch.float32
+    z = torch.empty((B, D), dtype=dtype, device=x.device)
+    target = torch.empty((B, D), dtype=torch.float32, device=x.device)
+    e_out = torch.empty_like(target) if (want_e and e is None) else None
+    if e is not None:
+        assert e.shape == x.shape and e.dtype == torch.float32 and e.is_contiguous()
+    _lib.check(_lib.lib().mfc_flow_prepare(_lib.dtype_code(dtype), B, D, x.data_ptr(), _lib.ptr(e), t.data_ptr(),
+                                           float(noise_min), float(noise_max), seed, step, row0, z.data_ptr(),
+                                           target.data_ptr(), _lib.ptr(e_out), _lib.stream_ptr()),
+               "mfc_flow_prepare")
+    return z, target, (e if e is not None else e_out)
+
+
+def flow_loss(u, target, *, dudt=None, n_tan=0, t=None, r=None, kind=0, mode=0, p=1.0, c=1e-3, Bglobal=None,
+              want_grad=True):
+    """Returns (loss scalar tensor, du or None, per-example pe)."""
+    B, D = u.shape
+    assert u.is_contiguous() and target.shape == u.shape and target.dtype == torch.float32
+    if dudt is not None:
+        assert dudt.dtype == u.dtype and dudt.is_contiguous() and dudt.shape[0] >= n_tan and dudt.shape[1] == D
+    dev = u.device
+    pe = torch.empty(B, dtype=torch.float32, device=dev)
+    seed = torch.empty(B, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    du = torch.empty_like(u) if want_grad else None
+    _lib.check(_lib.lib().mfc_flow_loss(_lib.dtype_code(u.dtype), kind, mode, B, B if Bglobal is None else Bglobal,
+                                        D, u.data_ptr(), _lib.ptr(dudt), n_tan, _lib.ptr(t), _lib.ptr(r),
+                                        target.data_ptr(), float(p), float(c), pe.data_ptr(), seed.data_ptr(),
+                                        loss.data_ptr(), _lib.ptr(du), _lib.stream_ptr()), "mfc_flow_loss")
+    return loss, du, pe
+
+
+def adamw(p, g, m, v, *, lr, wd, step, b1=0.9, b2=0.999, eps=1e-8, p_bf16=None, grad_scale=1.0):
+    assert p.dtype == torch.float32 and m.dtype == torch.float32 and v.dtype == torch.float32
+    assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+    assert g.numel() == p.numel() == m.numel() == v.numel()
+    if p_bf16 is not None:
+        assert p_bf16.dtype == torch.bfloat16 and p_bf16.is_contiguous() and p_bf16.numel() == p.numel()
+    _lib.check(_lib.lib().mfc_adamw(_lib.dtype_code(g.dtype), p.numel(), p.data_ptr(), _lib.ptr(p_bf16),
+                                    g.data_ptr(), float(grad_scale), m.data_ptr(), v.data_ptr(), float(lr),
+                                    float(b1), float(b2), float(eps), float(wd), int(step), _lib.stream_ptr()),
+               "mfc_adamw")
