@@ -1,0 +1,2 @@
+from .conv_flow import ConditionalConvFlow  # noqa: F401
+from .train_state import AdamW, TrainState, adamw  # noqa: F401

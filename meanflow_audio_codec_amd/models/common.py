@@ -1,0 +1,70 @@
+"""Shared host-side pieces of the velocity nets: parameter trees, initialisers, dtype policy.
+
+Parameters are a flat ``dict[str, torch.Tensor]`` keyed by the Flax path joined with ``/``
+(SURVEY Appendix B): ``Dense.kernel [in,out]``, ``Conv.kernel [kh,kw,in,out]``.  Masters are
+always fp32; in bf16 mode every *big* ``kernel`` additionally has a bf16 working copy that the
+HIP kernels read (``TrainState.work``).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .. import ops
+
+
+def lecun_normal_(t: torch.Tensor, fan_in: int, gen: torch.Generator) -> torch.Tensor:
+    """flax ``lecun_normal``: truncated normal (+-2 sigma) with variance 1/fan_in."""
+    std = math.sqrt(1.0 / fan_in) / 0.87962566103423978
+    torch.nn.init.trunc_normal_(t, 0.0, 1.0, -2.0, 2.0, generator=gen)
+    return t.mul_(std)
+
+
+def init_from_shapes(shapes: dict, seed: int, device, big_threshold: int = 1 << 22) -> dict:
+    """Initialise a flat ``name -> shape`` map.  kernels: lecun-normal; biases, GRN gamma/beta:
+    zeros; layer_scale_gamma: 1e-6 (models/conv_flow.py:41-42,99-103).  Initialiser parity with
+    Flax is unpinned by the reference."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    out = {}
+    for name, shape in shapes.items():
+        leaf = name.rsplit("/", 1)[-1]
+        if leaf == "kernel":
+            fan_in = math.prod(shape[:-1])
+            t = torch.empty(shape, dtype=torch.float32, device=device)
+            out[name] = lecun_normal_(t, fan_in, gen)
+        elif leaf == "layer_scale_gamma":
+            out[name] = torch.full(shape, 1e-6, dtype=torch.float32, device=device)
+        elif leaf in ("query_tokens", "condition_tokens"):
+            out[name] = torch.empty(shape, dtype=torch.float32, device=device).normal_(0, 0.02, generator=gen)
+        else:
+            out[name] = torch.zeros(shape, dtype=torch.float32, device=device)
+    return out
+
+
+def auto_splitk(M: int, N: int, K: int) -> int:
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if K < 2048 or tiles >= 256:
+        return 1
+    return max(1, min((K + 255) // 256, (1024 + tiles - 1) // tiles))
+
+
+def dense(x, w, b=None, *, bias_rows=None, out=None, alpha=1.0, residual=None, beta=1.0):
+    """x [M,K] @ w [K,N] (+ b on the first bias_rows rows) through mfc_gemm."""
+    M, K = x.shape
+    N = w.shape[1]
+    return ops.gemm(x, w, bias=b, bias_rows=bias_rows, out=out, alpha=alpha, residual=residual, beta=beta,
+                    splitk=auto_splitk(M, N, K))
+
+
+def dense_dx(dy, w, *, alpha=1.0, residual=None, beta=1.0, out=None):
+    """dx [M,K] = dy [M,N] @ w[K,N]^T."""
+    M, N = dy.shape
+    K = w.shape[0]
+    return ops.gemm(dy, w, trans_b=True, alpha=alpha, residual=residual, beta=beta, out=out,
+                    splitk=auto_splitk(M, K, N))
+
+
+def dense_dw(x, dy, *, alpha=1.0, out=None):
+    """dw [K,N] = x [M,K]^T @ dy [M,N]."""
+    return ops.gemm(x, dy, trans_a=True, alpha=alpha, out=out, splitk=1)

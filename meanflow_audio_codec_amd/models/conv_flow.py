@@ -1,0 +1,296 @@
+"""ConditionalConvFlow on MI355X -- host mirror of ``models/conv_flow.py``.
+
+Same constructor arguments and call signature as the reference
+(``ConditionalConvFlow`` :213-271, ``ConditionalConvNeXtBlock`` :123-205,
+``ConvNeXtBlock`` :53-115, ``GlobalResponseNormalization`` :14-45); all arithmetic
+runs in the HIP kernels behind the C ABI (``mfc_gemm``, ``mfc_cnx_*``,
+``mfc_time_embed``, ``mfc_gelu_*``).  Because there is no tracing autodiff here,
+the model also exposes the three passes the loss strategies need:
+
+* ``forward(..)``            primal only (v pass, sampling)
+* ``forward(.., xdot=..)``   primal + forward-mode tangent, row-stacked ``[x; xdot]`` so
+                             every weight tile is read once
+* ``backward(ctx, dout)``    reverse pass through the saved primal
+
+Deliberate fixes of reference defects: the model gets an ``encode``
+method (defect 2; a bottleneck encoder, unpinned -- see ``encode``); ``latent_proj`` is
+created at init time when ``latent_input_dim`` is given (defect 12).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .. import _lib, ops
+from .common import dense, dense_dw, dense_dx, init_from_shapes
+
+BOTTLENECK = 128  # models/conv_flow.py:142,153
+
+
+class ConvCtx:
+    """Saved primal activations of one forward pass (consumed by ``backward``)."""
+    __slots__ = ("R", "x_in", "a1", "g1", "a2", "g2", "H0", "O", "G", "q", "sc", "sh", "cond", "lat", "enc")
+
+    def __init__(self):
+        for k in self.__slots__:
+            setattr(self, k, None)
+
+
+class ConditionalConvFlow:
+    def __init__(self, noise_dimension: int, condition_dimension: int, num_blocks: int, latent_dimension: int,
+                 image_size: int = 28, use_grn: bool = True, num_latent_tokens: int = 32,
+                 latent_input_dim: int | None = None, dtype: torch.dtype = torch.float32):
+        if condition_dimension % 2:
+            raise ValueError(f"condition_dimension must be even, got {condition_dimension}")
+        if not use_grn:
+            raise NotImplementedError("use_grn=False is not implemented in the HIP path")
+        self.noise_dimension = noise_dimension
+        self.condition_dimension = condition_dimension
+        self.num_blocks = num_blocks
+        self.latent_dimension = latent_dimension
+        self.num_latent_tokens = num_latent_tokens
+        self.spatial_size = int(math.sqrt(noise_dimension))            # conv_flow.py:138
+        self.channels = min(16, condition_dimension // 4)              # conv_flow.py:139
+        if self.channels != 16:
+            raise _lib.MfcError("HIP ConvNeXt kernels implement C = 16 channels (condition_dimension >= 64); "
+                                f"got C = {self.channels}")
+        self.S = self.spatial_size ** 2 * self.channels
+        # the reference's train_flow feeds [B, latent_dimension] latents (trainers/train.py:367-370);
+        # proj/mnist_trial feeds [B, 32, latent] (:163-166).  latent_proj is sized for what is fed.
+        self.latent_input_dim = latent_dimension if latent_input_dim is None else latent_input_dim
+        self.dtype = dtype
+        self._ws = {}
+
+    # ------------------------------------------------------------------ params
+    def param_shapes(self) -> dict:
+        D, S, Cd, C = self.noise_dimension, self.S, self.condition_dimension, self.channels
+        sh = {}
+        for i in range(self.num_blocks):
+            b = f"blocks_{i}"
+            sh[f"{b}/input_proj1/kernel"] = (D, BOTTLENECK); sh[f"{b}/input_proj1/bias"] = (BOTTLENECK,)
+            sh[f"{b}/input_proj2/kernel"] = (BOTTLENECK, S); sh[f"{b}/input_proj2/bias"] = (S,)
+            sh[f"{b}/conditioning_layer/kernel"] = (Cd, 2 * C); sh[f"{b}/conditioning_layer/bias"] = (2 * C,)
+            cb = f"{b}/conv_block"
+            sh[f"{cb}/Conv_0/kernel"] = (3, 3, C, C); sh[f"{cb}/Conv_0/bias"] = (C,)
+            sh[f"{cb}/Conv_1/kernel"] = (1, 1, C, 2 * C); sh[f"{cb}/Conv_1/bias"] = (2 * C,)
+            sh[f"{cb}/GlobalResponseNormalization_0/gamma"] = (2 * C,)
+            sh[f"{cb}/GlobalResponseNormalization_0/beta"] = (2 * C,)
+            sh[f"{cb}/Conv_2/kernel"] = (1, 1, 2 * C, C); sh[f"{cb}/Conv_2/bias"] = (C,)
+            sh[f"{cb}/layer_scale_gamma"] = (C,)
+            sh[f"{b}/output_proj1/kernel"] = (S, BOTTLENECK); sh[f"{b}/output_proj1/bias"] = (BOTTLENECK,)
+            sh[f"{b}/output_proj2/kernel"] = (BOTTLENECK, D); sh[f"{b}/output_proj2/bias"] = (D,)
+        sh["latent_proj/kernel"] = (self.latent_input_dim, Cd); sh["latent_proj/bias"] = (Cd,)
+        sh["encoder/dense1/kernel"] = (D, BOTTLENECK); sh["encoder/dense1/bias"] = (BOTTLENECK,)
+        sh["encoder/dense2/kernel"] = (BOTTLENECK, self.latent_dimension)
+        sh["encoder/dense2/bias"] = (self.latent_dimension,)
+        return sh
+
+    def init(self, seed: int = 0, device="cuda") -> dict:
+        return init_from_shapes(self.param_shapes(), seed, device)
+
+    def compute_dtype_of(self, name: str) -> torch.dtype:
+        """Kernels the big GEMMs / MFMA conv read live in the model dtype; the conditioning
+        path (conditioning_layer, latent_proj, encoder/dense2) and every vector stay fp32."""
+        if not name.endswith("/kernel"):
+            return torch.float32
+        small = ("conditioning_layer/kernel", "latent_proj/kernel", "encoder/dense2/kernel")
+        return torch.float32 if name.endswith(small) else self.dtype
+
+    # ------------------------------------------------------------------ helpers
+    def _cnx_w(self, w: dict, i: int) -> dict:
+        cb = f"blocks_{i}/conv_block"
+        return {"conv_w": w[f"{cb}/Conv_0/kernel"], "conv_b": w[f"{cb}/Conv_0/bias"],
+                "exp_w": w[f"{cb}/Conv_1/kernel"], "exp_b": w[f"{cb}/Conv_1/bias"],
+                "grn_gamma": w[f"{cb}/GlobalResponseNormalization_0/gamma"],
+                "grn_beta": w[f"{cb}/GlobalResponseNormalization_0/beta"],
+                "con_w": w[f"{cb}/Conv_2/kernel"], "con_b": w[f"{cb}/Conv_2/bias"],
+                "ls": w[f"{cb}/layer_scale_gamma"]}
+
+    def _cnx_g(self, g: dict, i: int) -> dict:
+        return self._cnx_w(g, i)
+
+    def _buf(self, key, shape, dtype, device):
+        t = self._ws.get(key)
+        if t is None or t.shape != tuple(shape) or t.dtype != dtype or t.device != device:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self._ws[key] = t
+        return t
+
+    def release_workspace(self):
+        self._ws.clear()
+
+    # ------------------------------------------------------------------ conditioning
+    def encode(self, w: dict, x: torch.Tensor, ctx: ConvCtx | None = None) -> torch.Tensor:
+        """BUILD DECISION (reference defect 2): ``ConditionalConvFlow`` has no ``encode`` although every
+        loss strategy calls ``apply_fn(.., method="encode")`` (trainers/loss_strategies.py:99,167,250), and
+        the reference's encoders (MLPEncoder D->(D+L)/2, MLPMixerEncoder D->512*L) are 10^10-parameter
+        layers at D = 392704.  Here: Dense(D->128) -> GELU -> Dense(128->latent), the block's own
+        bottleneck pattern (models/conv_flow.py:142-146).  Unpinned by the reference."""
+        xt = x if x.dtype == self.dtype else ops.cast(x.contiguous(), self.dtype)
+        a = dense(xt, w["encoder/dense1/kernel"], w["encoder/dense1/bias"])
+        g = ops.gelu_fwd(a)
+        g32 = g if g.dtype == torch.float32 else ops.cast(g, torch.float32)
+        lat = dense(g32, w["encoder/dense2/kernel"], w["encoder/dense2/bias"])
+        if ctx is not None:
+            ctx.enc = (xt, a, g32)
+        return lat
+
+    def conditioning(self, w: dict, t: torch.Tensor, h: torch.Tensor, latents: torch.Tensor | None,
+                     want_dot: bool = False):
+        """cond = emb(t) + emb(h) (+ latent_proj(flatten(latents))), models/conv_flow.py:257-267; the
+        tangent w.r.t. (t, h) with (tdot, hdot) = (1, 1) when ``want_dot`` (latents carry no tangent)."""
+        add = None
+        if latents is not None:
+            lf = latents.reshape(latents.shape[0], -1).to(torch.float32).contiguous()
+            if lf.shape[1] != self.latent_input_dim:
+                raise ValueError(f"latents flatten to {lf.shape[1]} features, latent_proj expects "
+                                 f"{self.latent_input_dim}")
+            add = dense(lf, w["latent_proj/kernel"], w["latent_proj/bias"])
+        return ops.time_embed(t.reshape(-1).contiguous(), h.reshape(-1).contiguous(),
+                              self.condition_dimension, add=add, want_dot=want_dot)
+
+    # ------------------------------------------------------------------ passes
+    def new_ctx(self) -> ConvCtx:
+        return ConvCtx()
+
+    def forward(self, w: dict, x: torch.Tensor, cond: torch.Tensor, *, xdot: torch.Tensor | None = None,
+                cond_dot: torch.Tensor | None = None, latents=None, save: bool = False, ctx: ConvCtx | None = None):
+        """Velocity net on R rows.  ``xdot`` ([n_tan, D], n_tan <= R) carries the tangents of the FIRST
+        n_tan rows; returns (out [R,D], outdot [n_tan,D] | None, ctx | None)."""
+        _lib.require_cuda(x, cond)
+        R, D = x.shape
+        assert D == self.noise_dimension and x.dtype == self.dtype and cond.shape == (R, self.condition_dimension)
+        n_tan = 0 if xdot is None else xdot.shape[0]
+        assert n_tan <= R
+        Rt = R + n_tan
+        K, S, s, dev, T = self.num_blocks, self.S, self.spatial_size, x.device, self.dtype
+        X = self._buf(("X0", Rt), (Rt, D), T, dev) if not save else torch.empty((Rt, D), dtype=T, device=dev)
+        X[:R].copy_(x)
+        if n_tan:
+            X[R:].copy_(xdot)
+            cstack = torch.cat([cond, cond_dot[:n_tan]], 0).contiguous()
+        else:
+            cstack = cond
+        if not save:
+            ctx = None
+        if save:
+            ctx = ctx or ConvCtx()
+            ctx.R = R
+            ctx.x_in, ctx.a1, ctx.g1, ctx.a2, ctx.g2, ctx.G, ctx.q, ctx.sc, ctx.sh = ([] for _ in range(9))
+            ctx.cond = cond
+            # block i primal rows live at [i*R, (i+1)*R); its tangent rows spill into the head of block
+            # i+1's region and are dead before that region is written.
+            ctx.H0 = self._buf(("H0save", R, n_tan), (K * R + n_tan, S), T, dev)
+            ctx.O = self._buf(("Osave", R, n_tan), (K * R + n_tan, S), T, dev)
+        else:
+            H0s = self._buf(("H0", Rt), (Rt, S), T, dev)
+            Os = self._buf(("O", Rt), (Rt, S), T, dev)
+        for i in range(K):
+            b = f"blocks_{i}"
+            a1 = dense(X, w[f"{b}/input_proj1/kernel"], w[f"{b}/input_proj1/bias"], bias_rows=R)
+            g1 = ops.gelu_fwd(a1, act_rows=R)
+            H0 = ctx.H0[i * R:i * R + Rt] if save else H0s
+            O = ctx.O[i * R:i * R + Rt] if save else Os
+            dense(g1, w[f"{b}/input_proj2/kernel"], w[f"{b}/input_proj2/bias"], bias_rows=R, out=H0)
+            cp = dense(cstack, w[f"{b}/conditioning_layer/kernel"], w[f"{b}/conditioning_layer/bias"], bias_rows=R)
+            sc, sh = cp[:R, :16].contiguous(), cp[:R, 16:].contiguous()
+            cw = self._cnx_w(w, i)
+            Gs, qs = [], []
+            if n_tan:
+                scd, shd = cp[R:, :16].contiguous(), cp[R:, 16:].contiguous()
+                _, _, G, q = ops.cnx_forward(H0[:n_tan], sc[:n_tan], sh[:n_tan], cw, s, h0dot=H0[R:],
+                                             scaledot=scd, shiftdot=shd, out=O[:n_tan], outdot=O[R:])
+                Gs.append(G); qs.append(q)
+            if R > n_tan:
+                _, _, G, q = ops.cnx_forward(H0[n_tan:R], sc[n_tan:], sh[n_tan:], cw, s, out=O[n_tan:R])
+                Gs.append(G); qs.append(q)
+            a2 = dense(O, w[f"{b}/output_proj1/kernel"], w[f"{b}/output_proj1/bias"], bias_rows=R)
+            g2 = ops.gelu_fwd(a2, act_rows=R)
+            Xn = torch.empty((Rt, D), dtype=T, device=dev) if save else self._buf(("X", i & 1, Rt), (Rt, D), T, dev)
+            dense(g2, w[f"{b}/output_proj2/kernel"], w[f"{b}/output_proj2/bias"], bias_rows=R, out=Xn,
+                  alpha=1.0 / K, residual=X, beta=1.0)
+            if save:
+                ctx.x_in.append(X); ctx.a1.append(a1); ctx.g1.append(g1); ctx.a2.append(a2); ctx.g2.append(g2)
+                ctx.G.append(torch.cat(Gs, 0) if len(Gs) > 1 else Gs[0])
+                ctx.q.append(torch.cat(qs, 0) if len(qs) > 1 else qs[0])
+                ctx.sc.append(sc); ctx.sh.append(sh)
+            X = Xn
+        out = X[:R]
+        outdot = X[R:] if n_tan else None
+        return out, outdot, ctx
+
+    def backward(self, w: dict, ctx: ConvCtx, dout: torch.Tensor, grads: dict):
+        """Reverse pass through the saved primal.  Writes every block parameter's gradient into
+        ``grads`` (big kernels: overwritten in the model dtype; small fp32 leaves: overwritten too).
+        Returns (dx [R,D], dcond [R,cond] fp32)."""
+        R, K, S, s, T = ctx.R, self.num_blocks, self.S, self.spatial_size, self.dtype
+        D, dev = self.noise_dimension, dout.device
+        assert dout.shape == (R, D) and dout.dtype == T and dout.is_contiguous()
+        dX = dout
+        dcond = torch.zeros((R, self.condition_dimension), dtype=torch.float32, device=dev)
+        dO = self._buf(("dO", R), (R, S), T, dev)
+        dH0 = self._buf(("dH0", R), (R, S), T, dev)
+        dC1 = self._buf(("dC1", R), (R, S), T, dev)
+        for i in reversed(range(K)):
+            b = f"blocks_{i}"
+            x_in = ctx.x_in[i][:R]
+            a1, g1, a2, g2 = ctx.a1[i][:R], ctx.g1[i][:R], ctx.a2[i][:R], ctx.g2[i][:R]
+            H0, O = ctx.H0[i * R:(i + 1) * R], ctx.O[i * R:(i + 1) * R]
+            # out = (g2 W4 + b4)/K + x
+            dg2 = dense_dx(dX, w[f"{b}/output_proj2/kernel"], alpha=1.0 / K)
+            dense_dw(g2, dX, alpha=1.0 / K, out=grads[f"{b}/output_proj2/kernel"])
+            ops.colsum(dX, scale=1.0 / K, out=grads[f"{b}/output_proj2/bias"])
+            da2 = ops.gelu_bwd(a2, dg2)
+            dense_dx(da2, w[f"{b}/output_proj1/kernel"], out=dO)
+            dense_dw(O, da2, out=grads[f"{b}/output_proj1/kernel"])
+            ops.colsum(da2, out=grads[f"{b}/output_proj1/bias"])
+            # ConvNeXt interior
+            cg = self._cnx_g(grads, i)
+            for t_ in cg.values():
+                t_.zero_()
+            _, dsc, dsh = ops.cnx_backward(H0, ctx.sc[i], ctx.sh[i], self._cnx_w(w, i), s, ctx.G[i], ctx.q[i], dO, cg,
+                                           dh0=dH0, scratch=dC1)
+            dcp = torch.cat([dsc, dsh], 1).contiguous()
+            dense_dw(ctx.cond, dcp, out=grads[f"{b}/conditioning_layer/kernel"])
+            ops.colsum(dcp, out=grads[f"{b}/conditioning_layer/bias"])
+            dcond = dense_dx(dcp, w[f"{b}/conditioning_layer/kernel"], residual=dcond, beta=1.0)
+            # h0 = g1 W2 + b2
+            ops.colsum(dH0, out=grads[f"{b}/input_proj2/bias"])
+            dense_dw(g1, dH0, out=grads[f"{b}/input_proj2/kernel"])
+            dg1 = dense_dx(dH0, w[f"{b}/input_proj2/kernel"])
+            da1 = ops.gelu_bwd(a1, dg1)
+            dense_dw(x_in, da1, out=grads[f"{b}/input_proj1/kernel"])
+            ops.colsum(da1, out=grads[f"{b}/input_proj1/bias"])
+            dX = dense_dx(da1, w[f"{b}/input_proj1/kernel"], residual=dX, beta=1.0)
+        return dX, dcond, None
+
+    def backward_conditioning(self, w: dict, ctx: ConvCtx, dcond: torch.Tensor, latents, grads: dict, dlat=None):
+        """Gradients of latent_proj and of the bottleneck encoder from d(cond)."""
+        lf = latents.reshape(latents.shape[0], -1).to(torch.float32).contiguous()
+        dense_dw(lf, dcond, out=grads["latent_proj/kernel"])
+        ops.colsum(dcond, out=grads["latent_proj/bias"])
+        if ctx.enc is None:
+            return
+        xt, a, g32 = ctx.enc
+        dlat = dense_dx(dcond, w["latent_proj/kernel"])
+        dense_dw(g32, dlat, out=grads["encoder/dense2/kernel"])
+        ops.colsum(dlat, out=grads["encoder/dense2/bias"])
+        dg = dense_dx(dlat, w["encoder/dense2/kernel"])
+        dgT = dg if a.dtype == torch.float32 else ops.cast(dg, a.dtype)
+        da = ops.gelu_bwd(a, dgT)
+        dense_dw(xt, da, out=grads["encoder/dense1/kernel"])
+        ops.colsum(da, out=grads["encoder/dense1/bias"])
+
+    # reference-style call: apply({"params": w}, x, time[B,2], latents) / method="encode"
+    def apply(self, variables: dict, x: torch.Tensor, time: torch.Tensor | None = None,
+              latents: torch.Tensor | None = None, method: str | None = None) -> torch.Tensor:
+        w = variables["params"]
+        if method == "encode":
+            return self.encode(w, x)
+        cond, _ = self.conditioning(w, time[:, 0].contiguous(), time[:, 1].contiguous(), latents)
+        xt = x if x.dtype == self.dtype else ops.cast(x.contiguous(), self.dtype)
+        out, _, _ = self.forward(w, xt.contiguous(), cond)
+        return out.clone()
+
+    __call__ = apply

@@ -1,0 +1,91 @@
+"""TrainState + AdamW -- host mirror of ``models/train_state.py`` (a flax ``TrainState``) and of the
+``optax.adamw`` transformation the reference builds at ``trainers/train.py:236``.
+
+The update itself is the fused HIP kernel ``mfc_adamw`` (fp32 master, fp32 moments, optional bf16
+working copy).  Unlike flax the state is updated IN PLACE (13.7 B parameters cannot be copied per
+step); ``apply_gradients`` returns ``self`` so reference-style code ``state = state.apply_gradients(..)``
+keeps working.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from .. import ops
+
+
+@dataclass
+class AdamW:
+    """optax.adamw(learning_rate, weight_decay): b1=.9, b2=.999, eps=1e-8, decay on ALL leaves."""
+    learning_rate: float
+    weight_decay: float = 1e-4
+    b1: float = 0.9
+    b2: float = 0.999
+    eps: float = 1e-8
+
+
+def adamw(learning_rate: float, weight_decay: float = 1e-4, b1: float = 0.9, b2: float = 0.999,
+          eps: float = 1e-8) -> AdamW:
+    return AdamW(learning_rate, weight_decay, b1, b2, eps)
+
+
+class TrainState:
+    def __init__(self, apply_fn, params: dict, tx: AdamW, model=None, step: int = 0, opt_state=None):
+        self.apply_fn = apply_fn
+        self.params = params            # fp32 masters
+        self.tx = tx
+        self.model = model
+        self.step = step
+        self.opt_state = opt_state or {
+            "mu": {k: torch.zeros_like(v) for k, v in params.items()},
+            "nu": {k: torch.zeros_like(v) for k, v in params.items()},
+        }
+        self.work = {}                  # what the kernels read
+        self._grads = None
+        self.refresh_work()
+
+    @classmethod
+    def create(cls, *, apply_fn, params, tx, model=None):
+        return cls(apply_fn, params, tx, model=model)
+
+    def _work_dtype(self, name):
+        if self.model is not None and hasattr(self.model, "compute_dtype_of"):
+            return self.model.compute_dtype_of(name)
+        return torch.float32
+
+    def refresh_work(self):
+        for k, p in self.params.items():
+            dt = self._work_dtype(k)
+            if dt == torch.float32:
+                self.work[k] = p
+            else:
+                w = self.work.get(k)
+                if w is None or w.dtype != dt or w.shape != p.shape:
+                    w = torch.empty(p.shape, dtype=dt, device=p.device)
+                    self.work[k] = w
+                ops.cast(p, dt, out=w)
+
+    def grad_buffers(self) -> dict:
+        """Persistent gradient buffers: big kernels in the compute dtype (written once per step by the
+        weight-gradient GEMM), everything else fp32."""
+        if self._grads is None:
+            g = {}
+            for k, p in self.params.items():
+                dt = self._work_dtype(k)
+                if "/conv_block/" in k:
+                    dt = torch.float32   # accumulated with fp32 atomics by the spatial kernels
+                g[k] = torch.zeros(p.shape, dtype=dt, device=p.device)
+            self._grads = g
+        return self._grads
+
+    def apply_gradients(self, *, grads: dict, grad_scale: float = 1.0):
+        self.step += 1
+        tx = self.tx
+        for k, p in self.params.items():
+            g = grads[k]
+            w = self.work[k]
+            ops.adamw(p, g, self.opt_state["mu"][k], self.opt_state["nu"][k], lr=tx.learning_rate,
+                      wd=tx.weight_decay, step=self.step, b1=tx.b1, b2=tx.b2, eps=tx.eps,
+                      p_bf16=(w if w.dtype == torch.bfloat16 else None), grad_scale=grad_scale)
+        return self

@@ -1,0 +1,175 @@
+"""Loss strategies -- host mirror of ``trainers/loss_strategies.py``.
+
+``LossStrategy.compute_loss(state, key, x) -> (loss, grads)`` with the reference's names and
+constructor arguments.  There is no tracing autodiff: each strategy drives the model's explicit
+passes (primal / primal+tangent / reverse), all of which run in HIP kernels:
+
+* ImprovedMeanFlowLoss (:204-280): v = f(z,[t,0]) (no grad, only rows with r != t), then ONE
+  row-stacked pass [z; zdot=v] for (u, dudt) with tangent (v, 1, 0) -> th tangent (1, 1),
+  v_pred = u + (t-r) sg(dudt), weighted L2 / MSE, reverse pass through u only.
+* MeanFlowLoss (:115-201): tangent (e-x, 1, 0), u_tgt = v - clip(t-r,0,1) sg(dudt), adaptive weight.
+* FlowMatchingLoss (:50-112).
+
+Rows whose r == t multiply dudt by exactly 0 (:270), so their v / tangent passes are skipped
+(algorithmic 4 F_fwd instead of 5); rows are re-ordered so tangent rows come first.
+
+Extra keyword arguments (not in the reference): ``e, t, r`` to pass the random draws explicitly
+(parity tests), ``row0`` / ``global_batch`` for data-parallel shards (means are over the GLOBAL
+batch and the deterministic "first int(B*p) rows have r = t" rule of utils.sample_tr is applied
+per global row).
+"""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+
+import torch
+
+from .. import ops
+from .noise_schedules import LinearNoiseSchedule, NoiseSchedule
+from .time_sampling import LogitNormalTimeSampling, MeanFlowTimeSampling, PRNGKey, TimeSamplingStrategy
+
+
+class LossStrategy(ABC):
+    @abstractmethod
+    def compute_loss(self, state, key: PRNGKey, x: torch.Tensor, **kw):
+        ...
+
+
+def _prep_x(x):
+    if x.dtype != torch.float32:
+        x = x.float()
+    return x.reshape(x.shape[0], -1).contiguous()
+
+
+def _order_rows(t, r, B, row0, Bg, prop, sampled):
+    """Permutation putting rows with r != t first; returns (perm | None, n_tan)."""
+    if sampled:
+        ds = min(max(int(Bg * prop) - row0, 0), B)      # local rows [0, ds) have r == t
+        if ds == 0:
+            return None, B
+        if ds == B:
+            return None, 0
+        perm = torch.cat([torch.arange(ds, B), torch.arange(0, ds)]).to(t.device)
+        return perm, B - ds
+    mask = (t.reshape(-1) != r.reshape(-1))
+    n_tan = int(mask.sum().item())
+    if n_tan == B or n_tan == 0:
+        return None, n_tan
+    perm = torch.argsort((~mask).to(torch.int8), stable=True)
+    return perm, n_tan
+
+
+def _loss_mode(use_weighted_loss):
+    return 0 if use_weighted_loss else 1
+
+
+class FlowMatchingLoss(LossStrategy):
+    def __init__(self, noise_schedule: NoiseSchedule | None = None,
+                 time_sampling: TimeSamplingStrategy | None = None, use_weighted_loss: bool = True):
+        self.noise_schedule = noise_schedule or LinearNoiseSchedule()
+        self.time_sampling = time_sampling or LogitNormalTimeSampling()
+        self.use_weighted_loss = use_weighted_loss
+
+    def compute_loss(self, state, key, x, *, e=None, t=None, row0=0, global_batch=None, aux=None):
+        model, w = state.model, state.work
+        x = _prep_x(x)
+        B = x.shape[0]
+        Bg = global_batch or B
+        if t is None:
+            t = self.time_sampling.sample_time(key, B, row0=row0, global_batch=Bg, device=x.device)
+        t = t.reshape(B, 1).float().contiguous()
+        ns = self.noise_schedule
+        z, target, _ = ops.flow_prepare(x, t, model.dtype, ns.noise_min, ns.noise_max, e=e, seed=key.seed,
+                                        step=key.counter, row0=row0)
+        ctx_holder = model.new_ctx()
+        latents = model.encode(w, x, ctx_holder)
+        cond, _ = model.conditioning(w, t, torch.zeros_like(t), latents)
+        pred, _, ctx = model.forward(w, z, cond, latents=latents, save=True, ctx=ctx_holder)
+        loss, du, _ = ops.flow_loss(pred, target, kind=0, mode=_loss_mode(self.use_weighted_loss), Bglobal=Bg)
+        grads = state.grad_buffers()
+        _, dcond, dlat = model.backward(w, ctx, du, grads)
+        model.backward_conditioning(w, ctx, dcond, latents, grads, dlat=dlat)
+        if aux is not None:
+            aux.update(pred=pred, t=t)
+        return loss, grads
+
+
+class _TwoTimeLoss(LossStrategy):
+    kind = 0
+
+    def _run(self, state, key, x, e, t, r, row0, global_batch, aux, *, nmin, nmax, mode, p, c, use_v_pass):
+        model, w = state.model, state.work
+        x = _prep_x(x)
+        B = x.shape[0]
+        Bg = global_batch or B
+        sampled = t is None
+        if sampled:
+            t, r = self.time_sampling.sample_time_pair(key, B, row0=row0, global_batch=Bg, device=x.device)
+        t = t.reshape(B, 1).float().contiguous()
+        r = r.reshape(B, 1).float().contiguous()
+        perm, n_tan = _order_rows(t, r, B, row0, Bg, getattr(self.time_sampling, "data_proportion", 0.5), sampled)
+        if perm is not None:
+            x, t, r = x[perm].contiguous(), t[perm].contiguous(), r[perm].contiguous()
+            if e is not None:
+                e = e[perm].contiguous()
+        z, target, _ = ops.flow_prepare(x, t, model.dtype, nmin, nmax, e=e, seed=key.seed, step=key.counter,
+                                        row0=row0)
+        ctx_holder = model.new_ctx()
+        latents = model.encode(w, x, ctx_holder)
+        h = ops.axpby(1.0, t, -1.0, r)
+        cond_u, cdot = model.conditioning(w, t, h, latents, want_dot=n_tan > 0)
+        zdot = None
+        if n_tan > 0:
+            if use_v_pass:
+                # boundary-condition velocity v = f(z, [t, 0]) on the rows that need a tangent
+                lat_t = None if latents is None else latents[:n_tan]
+                cond_v, _ = model.conditioning(w, t[:n_tan].contiguous(), torch.zeros_like(t[:n_tan]), lat_t)
+                v, _, _ = model.forward(w, z[:n_tan], cond_v, latents=lat_t)
+                zdot = v
+            else:
+                zdot = ops.cast(target[:n_tan].contiguous(), model.dtype)  # MeanFlow: tangent (e - x)
+        u, dudt, ctx = model.forward(w, z, cond_u, xdot=zdot, cond_dot=cdot, latents=latents, save=True,
+                                     ctx=ctx_holder)
+        loss, du, _ = ops.flow_loss(u, target, dudt=dudt, n_tan=n_tan, t=t, r=r, kind=self.kind, mode=mode, p=p,
+                                    c=c, Bglobal=Bg)
+        grads = state.grad_buffers()
+        _, dcond, dlat = model.backward(w, ctx, du, grads)
+        model.backward_conditioning(w, ctx, dcond, latents, grads, dlat=dlat)
+        if aux is not None:
+            inv = None if perm is None else torch.argsort(perm)
+            un = (lambda a: a) if inv is None else (lambda a: a[inv])
+            aux.update(u=un(u), t=un(t), r=un(r), n_tan=n_tan,
+                       dudt=dudt, perm=perm, v=(zdot if use_v_pass else None))
+        return loss, grads
+
+
+class MeanFlowLoss(_TwoTimeLoss):
+    """trainers/loss_strategies.py:115-201 (uniform interpolation regardless of noise_schedule, :156-160)."""
+    kind = 1
+
+    def __init__(self, noise_schedule: NoiseSchedule | None = None,
+                 time_sampling: MeanFlowTimeSampling | None = None, gamma: float = 0.5, c: float = 1e-3):
+        self.noise_schedule = noise_schedule or LinearNoiseSchedule()
+        self.time_sampling = time_sampling or MeanFlowTimeSampling()
+        self.gamma = gamma
+        self.c = c
+
+    def compute_loss(self, state, key, x, *, e=None, t=None, r=None, row0=0, global_batch=None, aux=None):
+        return self._run(state, key, x, e, t, r, row0, global_batch, aux, nmin=0.0, nmax=1.0, mode=2,
+                         p=1.0 - self.gamma, c=self.c, use_v_pass=False)
+
+
+class ImprovedMeanFlowLoss(_TwoTimeLoss):
+    """trainers/loss_strategies.py:204-280."""
+    kind = 0
+
+    def __init__(self, noise_schedule: NoiseSchedule | None = None,
+                 time_sampling: MeanFlowTimeSampling | None = None, use_weighted_loss: bool = True):
+        self.noise_schedule = noise_schedule or LinearNoiseSchedule()
+        self.time_sampling = time_sampling or MeanFlowTimeSampling()
+        self.use_weighted_loss = use_weighted_loss
+
+    def compute_loss(self, state, key, x, *, e=None, t=None, r=None, row0=0, global_batch=None, aux=None):
+        ns = self.noise_schedule
+        return self._run(state, key, x, e, t, r, row0, global_batch, aux, nmin=ns.noise_min, nmax=ns.noise_max,
+                         mode=_loss_mode(self.use_weighted_loss), p=1.0, c=1e-3, use_v_pass=True)

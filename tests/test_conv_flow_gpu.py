@@ -1,0 +1,144 @@
+"""GPU parity: ConditionalConvFlow passes and the loss strategies vs the fp64 oracle."""
+import pytest
+import torch
+
+from oracle import flow_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+D, CD, LAT, NB = 400, 128, 24, 2      # s = 20, C = 16, S = 6400
+
+
+def _make(dtype, seed=0, special=False):
+    from meanflow_audio_codec_amd.models import ConditionalConvFlow, TrainState, adamw
+    model = ConditionalConvFlow(D, CD, NB, LAT, dtype=dtype)
+    shapes = fo.conv_flow_shapes(D, CD, LAT, NB, latent_dim=LAT)
+    p64 = fo.init_params(shapes, seed=seed, special=special)
+    flat = {k: v.float().cuda().contiguous() for k, v in fo.flatten(p64).items()}
+    assert set(flat) == set(model.param_shapes()), set(flat) ^ set(model.param_shapes())
+    for k, shp in model.param_shapes().items():
+        assert tuple(flat[k].shape) == tuple(shp), k
+    state = TrainState.create(apply_fn=model.apply, params=flat, tx=adamw(1e-3, 1e-2), model=model)
+    # the oracle sees the parameters the kernels see (bf16-rounded big kernels in bf16 mode)
+    pq = fo.unflatten({k: state.work[k].double().cpu() for k in flat})
+    return model, state, pq
+
+
+def _rel(a, b):
+    return ((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 5e-2)])
+def test_apply_matches_oracle(dtype, tol):
+    model, state, pq = _make(dtype)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(5, D, generator=g)
+    time = torch.rand(5, 2, generator=g)
+    lat = torch.randn(5, LAT, generator=g)
+    ref = fo.conv_flow_apply(pq, x.to(dtype).double(), time.double(), lat.double())
+    out = model.apply({"params": state.work}, x.cuda(), time.cuda(), lat.cuda())
+    assert _rel(out, ref) < tol
+    ref0 = fo.conv_flow_apply(pq, x.to(dtype).double(), time.double(), None)
+    out0 = model.apply({"params": state.work}, x.cuda(), time.cuda(), None)
+    assert _rel(out0, ref0) < tol
+    enc = model.apply({"params": state.work}, x.cuda(), method="encode")
+    assert _rel(enc, fo.conv_flow_encode(pq, x.to(dtype).double())) < tol
+
+
+def _draws(B, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, D, generator=g)
+    e = torch.randn(B, D, generator=g)
+    t, r = fo.sample_tr_from_normals(torch.randn(B, 1, generator=g, dtype=torch.float64),
+                                     torch.randn(B, 1, generator=g, dtype=torch.float64))
+    return x, e, t.float(), r.float()
+
+
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, 2e-3), (torch.bfloat16, 5e-2, 0.15)])
+def test_improved_mean_flow_loss_and_grads(dtype, tol, gtol):
+    from meanflow_audio_codec_amd.trainers import ImprovedMeanFlowLoss, PRNGKey
+    model, state, pq = _make(dtype)
+    x, e, t, r = _draws(6)
+    loss_ref, g_ref, aux_ref = fo.imf_loss(fo.conv_flow_apply, fo.conv_flow_encode, pq, x.double(), e.double(),
+                                           t.double(), r.double())
+    aux = {}
+    loss, grads = ImprovedMeanFlowLoss().compute_loss(state, PRNGKey(0), x.cuda(), e=e.cuda(), t=t.cuda(),
+                                                      r=r.cuda(), aux=aux)
+    assert aux["n_tan"] == 3
+    assert _rel(aux["u"], aux_ref["u"]) < tol
+    assert abs(loss.item() - loss_ref.item()) < tol * max(1.0, abs(loss_ref.item()))
+    gr = fo.flatten(g_ref)
+    errs = {k: _rel(grads[k], gr[k]) for k in gr if gr[k].abs().max() > 0}
+    bad = {k: v for k, v in errs.items() if not v < gtol}
+    assert not bad, bad
+    # reference property test/test_improved_mean_flow.py:31-54: t == r  =>  v_pred == u  (no tangent rows)
+    aux2 = {}
+    ImprovedMeanFlowLoss().compute_loss(state, PRNGKey(0), x.cuda(), e=e.cuda(), t=t.cuda(), r=t.cuda(), aux=aux2)
+    assert aux2["n_tan"] == 0 and aux2["dudt"] is None
+
+
+def test_jvp_matches_reverse_mode_property():
+    """test/test_improved_mean_flow.py:57-100 restated on the HIP passes (fp32, 1e-4 relative):
+    sum(dudt) for tangent (v, 1, 0) == <grad_z sum(u), v> + sum(grad_t sum(u))."""
+    from meanflow_audio_codec_amd import ops
+    model, state, pq = _make(torch.float32, seed=2)
+    w = state.work
+    g = torch.Generator().manual_seed(2)
+    B = 3
+    z = torch.randn(B, D, generator=g).cuda()
+    t = torch.rand(B, 1, generator=g).cuda()
+    r = 0.5 * t
+    v = torch.randn(B, D, generator=g)
+    v = (v / v.norm()).cuda()
+    cond, cdot = model.conditioning(w, t, t - r, None, want_dot=True)
+    u, dudt, ctx = model.forward(w, z, cond, xdot=v, cond_dot=cdot, save=True)
+    lhs = dudt.double().sum().item()
+    grads = state.grad_buffers()
+    dz, dcond, _ = model.backward(w, ctx, torch.ones_like(u), grads)
+    rhs = (dz.double() * v.double()).sum().item() + (dcond.double() * cdot.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs)), (lhs, rhs)
+
+
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-4, 2e-3)])
+def test_flow_matching_and_mean_flow_losses(dtype, tol, gtol):
+    from meanflow_audio_codec_amd.trainers import FlowMatchingLoss, MeanFlowLoss, PRNGKey
+    model, state, pq = _make(dtype, seed=4)
+    x, e, t, r = _draws(4, seed=8)
+    loss_ref, g_ref, _ = fo.fm_loss(fo.conv_flow_apply, fo.conv_flow_encode, pq, x.double(), e.double(), t.double())
+    loss, grads = FlowMatchingLoss().compute_loss(state, PRNGKey(0), x.cuda(), e=e.cuda(), t=t.cuda())
+    assert abs(loss.item() - loss_ref.item()) < tol
+    gr = fo.flatten(g_ref)
+    bad = {k: _rel(grads[k], gr[k]) for k in gr if gr[k].abs().max() > 0 and not _rel(grads[k], gr[k]) < gtol}
+    assert not bad, bad
+    loss_ref, g_ref, _ = fo.mf_loss(fo.conv_flow_apply, fo.conv_flow_encode, pq, x.double(), e.double(), t.double(),
+                                    r.double())
+    loss, grads = MeanFlowLoss().compute_loss(state, PRNGKey(0), x.cuda(), e=e.cuda(), t=t.cuda(), r=r.cuda())
+    assert abs(loss.item() - loss_ref.item()) < tol
+    gr = fo.flatten(g_ref)
+    bad = {k: _rel(grads[k], gr[k]) for k in gr if gr[k].abs().max() > 0 and not _rel(grads[k], gr[k]) < gtol}
+    assert not bad, bad
+
+
+def test_train_step_updates_like_oracle():
+    from meanflow_audio_codec_amd.trainers import ImprovedMeanFlowLoss, PRNGKey, train_step
+    model, state, pq = _make(torch.float32, seed=6)
+    x, e, t, r = _draws(4, seed=9)
+    _, g_ref, _ = fo.imf_loss(fo.conv_flow_apply, fo.conv_flow_encode, pq, x.double(), e.double(), t.double(),
+                              r.double())
+    strat = ImprovedMeanFlowLoss()
+    before = {k: v.clone() for k, v in state.params.items()}
+
+    class Fixed(ImprovedMeanFlowLoss):
+        def compute_loss(self, state, key, xx, **kw):
+            return super().compute_loss(state, key, xx, e=e.cuda(), t=t.cuda(), r=r.cuda())
+    key = PRNGKey(0)
+    state, loss, key2 = train_step(state, key, x.cuda(), Fixed())
+    assert key2.counter == key.counter + 1 and state.step == 1
+    gr = fo.flatten(g_ref)
+    for k in ("blocks_0/input_proj2/kernel", "blocks_1/conv_block/Conv_0/kernel", "blocks_1/output_proj2/bias",
+              "latent_proj/kernel", "encoder/dense1/kernel"):
+        p0 = before[k].double().cpu()
+        pn, _, _ = fo.adamw_step(p0, gr[k], torch.zeros_like(p0), torch.zeros_like(p0), 1, 1e-3, 1e-2)
+        # step 1 of Adam moves every weight by ~lr*sign(g): compare where |g| is not tiny
+        mask = gr[k].abs() > 1e-3 * gr[k].abs().max()
+        assert ((state.params[k].double().cpu() - pn)[mask].abs().max() < 2e-5), k
