@@ -1,0 +1,337 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X MeanFlow-audio-codec hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload literal|ci] [--dtype bf16|f32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json config #4/#5): method=improved_mean_flow, architecture=convnet, dataset=audio
+(synthetic 24 kHz clips, T=196608 = 8.192 s), tokenization=mdct (window 512, hop 256 -> D=392704),
+condition 128 / latent 256 / 8 blocks (13.70 B parameters), batch 128 PER GPU (weak scaling), bf16
+compute with fp32 master weights, AdamW lr 1e-4 wd 1e-4.
+
+A "step" = MDCT tokenise -> iMF loss (v pass, row-stacked primal+tangent pass, reverse pass) -> [DP
+all-reduce] -> AdamW, with the synthetic clips already resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s   (MI355X_MICROARCH.md: 8 TB/s spec)
+MFMA_PEAK = {"bf16": 2.5e15, "f32": 157.3e12}
+
+WORKLOADS = {
+    # BASELINE config #4: the literal shipped config
+    "literal": dict(T=196608, window=512, hop=256, cond=128, latent=256, blocks=8, batch=128, sr=24000),
+    # CI / parity shape of SURVEY 8(d): same code, T=16384 -> D=32256, 1.12 B parameters
+    "ci": dict(T=16384, window=512, hop=256, cond=128, latent=256, blocks=8, batch=16, sr=24000),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="literal", choices=list(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's 128)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--decode-batch", type=int, default=None)
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------
+# algorithmic work per C-ABI call (SURVEY 8d figures, restated per kernel in DESIGN.md)
+# ---------------------------------------------------------------------------------------------
+def algorithmic_work(name, ints, nn):
+    """-> (bytes, flops, dtype_code) for one launch; None if the call is not modelled."""
+    if name == "mfc_gemm":
+        dt, flags, M, N, K = ints[:5]
+        es = 4 if dt == 0 else 2
+        has_res = nn[5] if len(nn) > 5 else False
+        return es * (M * K + K * N + M * N * (2 if has_res else 1)), 2.0 * M * N * K, dt
+    if name.startswith("mfc_cnx_"):
+        dt, R, s = ints[:3]
+        es = 4 if dt == 0 else 2
+        px = R * s * s
+        conv, exp, con = 2 * 9 * 16 * 16, 2 * 16 * 32, 2 * 32 * 16
+        if name == "mfc_cnx_stats":
+            j = 2 if nn[1] else 1
+            return es * px * 16 * j, float(px) * (conv + exp) * j, dt
+        if name == "mfc_cnx_apply":
+            j = 2 if nn[1] else 1
+            return es * px * 16 * 2 * j, float(px) * (conv + exp + con) * j, dt
+        if name == "mfc_cnx_bwd_stats":
+            return es * px * 16 * 2, float(px) * (conv + exp + con), dt
+        if name == "mfc_cnx_bwd_main":
+            return es * px * 16 * 3, float(px) * (conv + 2 * exp + 2 * con + con + exp + con), dt
+        if name == "mfc_cnx_bwd_conv":
+            return es * px * 16 * 4, float(px) * 2 * conv, dt
+    if name == "mfc_adamw":
+        dt, n = ints[0], ints[1]
+        ges = 4 if dt == 0 else 2
+        return n * (12 + 12 + ges + (2 if nn[1] else 0)), 6.0 * n, 0
+    if name == "mfc_mdct_fwd":
+        B, T, ldx, N, hop = ints[:5]
+        nf = 1 if T < N else (T - N) // hop + 1
+        return 4 * B * (T + nf * N), 0.0, 0
+    if name == "mfc_mdct_inv":
+        B, nf, N, hop = ints[:4]
+        return 4 * B * (nf * N + (nf - 1) * hop + 2 * N), 0.0, 0
+    return None
+
+
+def kernel_of(name, ints):
+    if name == "mfc_gemm":
+        dt, flags, M, N, K = ints[:5]
+        return f"gemm_kernel<{'f32' if dt == 0 else 'bf16'},TA={flags & 1},TB={(flags >> 1) & 1}> M={M} N={N} K={K}"
+    return name.replace("mfc_", "") + "_kernel"
+
+
+def summarize_timing(records, steps):
+    agg = {}
+    for name, ints, nn, s, e in records:
+        key = (name, ints, nn)
+        ms = s.elapsed_time(e)
+        a = agg.setdefault(key, [0.0, 0])
+        a[0] += ms
+        a[1] += 1
+    rows = []
+    for (name, ints, nn), (ms, cnt) in agg.items():
+        rows.append(dict(name=name, ints=ints, nn=nn, total_ms=ms, launches=cnt, avg_ms=ms / cnt,
+                         per_step_ms=ms / steps))
+    rows.sort(key=lambda r: -r["total_ms"])
+    return rows
+
+
+def roofline_of(row, dtype_name):
+    w = algorithmic_work(row["name"], row["ints"], row["nn"])
+    if w is None:
+        return None
+    nbytes, flops, dt = w
+    dur = row["avg_ms"] * 1e-3
+    peak_f = MFMA_PEAK["f32" if dt == 0 else "bf16"]
+    t_h, t_f = nbytes / HBM_PEAK, flops / peak_f
+    if t_h >= t_f:
+        ach = nbytes / dur / 1e9
+        return dict(kernel=kernel_of(row["name"], row["ints"]), bound="hbm", achieved=round(ach, 1),
+                    peak=HBM_PEAK / 1e9, unit="GB/s", frac=round(ach / (HBM_PEAK / 1e9), 4), traffic=None,
+                    algorithmic_bytes=int(nbytes), algorithmic_flops=float(flops),
+                    avg_launch_ms=round(row["avg_ms"], 4), launches_per_step=row["launches"])
+    ach = flops / dur / 1e12
+    return dict(kernel=kernel_of(row["name"], row["ints"]), bound="mfma", achieved=round(ach, 2),
+                peak=peak_f / 1e12, unit="TFLOP/s", frac=round(ach / (peak_f / 1e12), 4), traffic=None,
+                algorithmic_bytes=int(nbytes), algorithmic_flops=float(flops),
+                avg_launch_ms=round(row["avg_ms"], 4), launches_per_step=row["launches"])
+
+
+# ---------------------------------------------------------------------------------------------
+def conv_flow_flops_fwd(D, blocks=8, cond=128, C=16):
+    s = int(math.sqrt(D))
+    S = s * s * C
+    return blocks * (2 * 128 * (2 * D + 2 * S) + s * s * 2 * (9 * C * C + 4 * C * C) + 2 * cond * 2 * C)
+
+
+def cpu_baseline(wl_literal, seconds_budget=25.0):
+    """The oracle (a CPU restatement, kind="port") timed on the host cores on a BOUNDED sample: the
+    CI shape (T=16384 -> D=32256, 1.12 B parameters), fp32, then scaled to the literal shape by the
+    per-sample FLOP ratio (SURVEY 8d / BASELINE.md section 3)."""
+    from oracle import flow_oracle as fo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    D = 63 * 512
+    B = 2
+    shapes = fo.conv_flow_shapes(D, 128, 256, 8, latent_dim=256)
+    params = fo.init_params(shapes, seed=0, dtype=torch.float32)
+    flat = fo.flatten(params)
+    m = {k: torch.zeros_like(v) for k, v in flat.items()}
+    v = {k: torch.zeros_like(p) for k, p in flat.items()}
+    g = torch.Generator().manual_seed(0)
+    x = 0.1 * torch.randn(B, D, generator=g)
+    e = torch.randn(B, D, generator=g)
+    t, r = fo.sample_tr_from_normals(torch.randn(B, 1, generator=g), torch.randn(B, 1, generator=g))
+
+    def step(i):
+        nonlocal params, flat
+        loss, grads, _ = fo.imf_loss(fo.conv_flow_apply, fo.conv_flow_encode, params, x, e, t, r)
+        gf = fo.flatten(grads)
+        for k in flat:
+            flat[k], m[k], v[k] = fo.adamw_step(flat[k], gf[k], m[k], v[k], i + 1, 1e-4, 1e-4)
+        params = fo.unflatten(flat)
+
+    t0 = time.perf_counter()
+    step(0)  # first step (includes one-off thread-pool / allocator warm-up)
+    warm = time.perf_counter() - t0
+    n = max(0, min(3, int(seconds_budget / max(warm, 1e-3)) - 1))
+    if n == 0:
+        dt, n = warm, 1       # a single step already uses the budget: report it
+    else:
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(i + 1)
+        dt = (time.perf_counter() - t0) / n
+    ci_sps = B / dt
+    scale = conv_flow_flops_fwd(D) / conv_flow_flops_fwd(767 * 512)
+    return dict(value=round(ci_sps * scale, 5), unit="samples/s", cores=cores, kind="port",
+                sample=(f"oracle/flow_oracle.py iMF step (fwd+jvp+bwd+AdamW), torch-CPU fp32, {n} timed step(s) of "
+                        f"batch {B} at the CI shape T=16384 (D={D}, 1.12 B params): {ci_sps:.3f} samples/s, "
+                        f"scaled by the per-sample FLOP ratio {scale:.4f} to the literal shape"))
+
+
+# ---------------------------------------------------------------------------------------------
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from meanflow_audio_codec_amd import _build, _lib
+    if not _lib.LIB_PATH.exists():
+        _build.build(verbose=False)
+    from meanflow_audio_codec_amd.distributed import GradReducer
+    from meanflow_audio_codec_amd.evaluators import GraphedDecoder
+    from meanflow_audio_codec_amd.models import ConditionalConvFlow, TrainState, adamw
+    from meanflow_audio_codec_amd.preprocessing import MDCTConfig, MDCTTokenization
+    from meanflow_audio_codec_amd.trainers import (ImprovedMeanFlowLoss, LinearNoiseSchedule, MeanFlowTimeSampling,
+                                                   PRNGKey, train_step)
+
+    wl = dict(WORKLOADS[args.workload])
+    B = args.batch or wl["batch"]
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    tok = MDCTTokenization(config=MDCTConfig(window_size=wl["window"], hop_size=wl["hop"]))
+    n_tok, tok_dim = tok.token_shape(wl["T"])
+    D = n_tok * tok_dim
+
+    model = ConditionalConvFlow(D, wl["cond"], wl["blocks"], wl["latent"], dtype=dtype)
+    params = model.init(seed=42, device=device)          # same weights on every rank
+    n_params = sum(p.numel() for p in params.values())
+    state = TrainState.create(apply_fn=model.apply, params=params, tx=adamw(1e-4, 1e-4), model=model)
+    strat = ImprovedMeanFlowLoss(LinearNoiseSchedule(0.001, 0.999), MeanFlowTimeSampling(-0.4, 1.0, 0.5), True)
+    reducer = GradReducer() if world > 1 else None
+    g = torch.Generator(device=device).manual_seed(42 + rank)
+    clips = 0.1 * torch.randn(B, wl["T"], generator=g, device=device)
+    key = PRNGKey(42)
+
+    def one_step(state, key):
+        tokens = tok.tokenize(clips)
+        return train_step(state, key, tokens.reshape(B, -1), strat, reducer=reducer, row0=rank * B,
+                          global_batch=world * B)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    losses = []
+    for _ in range(args.warmup):
+        state, loss, key = one_step(state, key)
+    barrier()
+    _lib.enable_timing()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        state, loss, key = one_step(state, key)
+        losses.append(loss)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    records = _lib.disable_timing()
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    loss_vals = [float(l) for l in losses]
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    out = {
+        "metric": "train samples/sec, iMF convnet MDCT (1-NFE decode audio-sec/sec in decode_audio_s_per_s)",
+        "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.workload}: improved_mean_flow+convnet+audio+mdct, T={wl['T']} "
+                               f"(N={wl['window']}, hop={wl['hop']} -> D={D}), cond={wl['cond']}, latent={wl['latent']}, "
+                               f"blocks={wl['blocks']}, {n_params / 1e9:.2f} B params, AdamW fp32 master",
+                   "per_gpu_batch": B, "global_batch": world * B, "parallelism": f"dp{world}"},
+        "loss": loss_vals,
+    }
+
+    if rank == 0:
+        # per-kernel timing over the timed region (HIP events on the launch stream)
+        rows = summarize_timing(records, args.steps)
+        dom = None
+        for row in rows:
+            rf = roofline_of(row, args.dtype)
+            if rf is not None:
+                dom = rf
+                dom["share_of_step"] = round(row["per_step_ms"] / ms_per_step, 4)
+                break
+        out["roofline"] = dom
+        out["top_kernels"] = [
+            dict(kernel=kernel_of(r["name"], r["ints"]), per_step_ms=round(r["per_step_ms"], 3),
+                 launches=r["launches"], avg_ms=round(r["avg_ms"], 4),
+                 **({k: v for k, v in (roofline_of(r, args.dtype) or {}).items() if k in ("bound", "frac")}))
+            for r in rows[:12]]
+        flops_alg = 4.0 * conv_flow_flops_fwd(D, wl["blocks"], wl["cond"])
+        out["step_model"] = {"algorithmic_gflop_per_sample": round(flops_alg / 1e9, 2),
+                             "achieved_tflops_algorithmic": round(flops_alg * value / world / 1e12, 2)}
+
+    # ---- 1-NFE decode (hipGraph): noise -> u(eps,[1,1]) -> IMDCT; replicas only under DP
+    if not args.no_decode:
+        try:
+            Bd = args.decode_batch or B
+            state._grads = None                      # training buffers are not needed for serving
+            model.release_workspace()
+            torch.cuda.empty_cache()
+            lat = torch.zeros(Bd, wl["latent"], device=device)       # trainers/train.py:367-370
+            dec = GraphedDecoder(model, state.work, Bd, lat, n_steps=0, token_shape=(n_tok, tok_dim),
+                                 mdct_config=tok.config, seed=42, device=device)
+            for _ in range(2):
+                dec()
+            barrier()
+            t0 = time.perf_counter()
+            nrep = max(3, args.steps)
+            for _ in range(nrep):
+                audio = dec()
+            barrier()
+            dsec = (time.perf_counter() - t0) / nrep
+            out["decode_audio_s_per_s"] = round(world * Bd * (wl["T"] / wl["sr"]) / dsec, 1)
+            out["decode_ms_per_batch"] = round(dsec * 1e3, 3)
+            out["decode_batch_per_gpu"] = Bd
+            out["decode_finite"] = bool(torch.isfinite(audio).all().item())
+        except Exception as ex:  # report, never hide
+            out["decode_error"] = repr(ex)[:300]
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        except Exception as ex:
+            out["cpu_baseline"] = {"error": repr(ex)[:300]}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

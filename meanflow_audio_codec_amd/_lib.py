@@ -79,8 +79,55 @@ def header_symbols() -> list[str]:
     return sorted(set(re.findall(r"\b(mfc_[a-z0-9_]+)\s*\(", txt)))
 
 
-def lib() -> ctypes.CDLL:
-    global _lib
+# ---- optional per-call HIP-event timing (used by bench.py for the roofline line) ----
+_timing = None  # list of (name, int-args, non-null-pointer mask, start_event, end_event) while enabled
+
+
+def enable_timing():
+    global _timing
+    _timing = []
+
+
+def disable_timing():
+    global _timing
+    rec, _timing = _timing, None
+    return rec or []
+
+
+class _Proxy:
+    """Forwards to the CDLL; with timing enabled brackets every launching call with HIP events
+    recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self, cdll):
+        self._c = cdll
+
+    def __getattr__(self, name):
+        fn = getattr(self._c, name)
+        if _timing is None or name not in SIGNATURES or SIGNATURES[name][0] is not c_int:
+            return fn
+        argtypes = SIGNATURES[name][1]
+
+        def timed(*args):
+            ints = tuple(int(a) for a, ty in zip(args, argtypes) if ty in (c_int, c_int64) and a is not None)
+            nn = tuple(bool(a) for a, ty in zip(args, argtypes) if ty is c_void_p)
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = fn(*args)
+            e.record()
+            if _timing is not None:
+                _timing.append((name, ints, nn, s, e))
+            return rc
+        return timed
+
+
+_proxy = None
+
+
+def lib():
+    global _lib, _proxy
+    if _proxy is not None:
+        return _proxy
     if _lib is None:
         if not LIB_PATH.exists():
             raise MfcError(
@@ -92,7 +139,8 @@ def lib() -> ctypes.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = l
-    return _lib
+    _proxy = _Proxy(_lib)
+    return _proxy
 
 
 def check(rc: int, what: str) -> None:

@@ -235,13 +235,13 @@ def init_params(shapes, seed=0, dtype=torch.float64, special=True):
         shape = t
         if name == "kernel":
             fan_in = math.prod(shape[:-1])
-            return (torch.randn(shape, generator=g, dtype=torch.float64) / math.sqrt(fan_in)).to(dtype)
+            return torch.randn(shape, generator=g, dtype=dtype) / math.sqrt(fan_in)
         if special:
             if name == "layer_scale_gamma":
                 return torch.full(shape, 1e-6, dtype=dtype)
             return torch.zeros(shape, dtype=dtype)
         scale = {"bias": 0.1, "gamma": 0.5, "beta": 0.1, "layer_scale_gamma": 0.5}[name]
-        return (scale * torch.randn(shape, generator=g, dtype=torch.float64)).to(dtype)
+        return scale * torch.randn(shape, generator=g, dtype=dtype)
 
     return rec(shapes, "")
 
