@@ -39,6 +39,14 @@ WORKLOADS = {
 }
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    """progress to stderr (the JSON line on stdout stays alone)"""
+    print(f"[bench +{time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +112,8 @@ def kernel_of(name, ints):
 def summarize_timing(records, steps):
     agg = {}
     for name, ints, nn, s, e in records:
+        if name == "mfc_adamw":
+            ints = ints[:2]          # drop the step counter from the key
         key = (name, ints, nn)
         ms = s.elapsed_time(e)
         a = agg.setdefault(key, [0.0, 0])
@@ -150,8 +160,13 @@ def cpu_baseline(wl_literal, seconds_budget=25.0):
     CI shape (T=16384 -> D=32256, 1.12 B parameters), fp32, then scaled to the literal shape by the
     per-sample FLOP ratio (SURVEY 8d / BASELINE.md section 3)."""
     from oracle import flow_oracle as fo
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))       # the GPU box gives 16 CPUs per GPU; never oversubscribe
     torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} threads")
     D = 63 * 512
     B = 2
     shapes = fo.conv_flow_shapes(D, 128, 256, 8, latent_dim=256)
@@ -172,9 +187,11 @@ def cpu_baseline(wl_literal, seconds_budget=25.0):
             flat[k], m[k], v[k] = fo.adamw_step(flat[k], gf[k], m[k], v[k], i + 1, 1e-4, 1e-4)
         params = fo.unflatten(flat)
 
+    log("cpu baseline: parameters ready, timing the first step")
     t0 = time.perf_counter()
     step(0)  # first step (includes one-off thread-pool / allocator warm-up)
     warm = time.perf_counter() - t0
+    log(f"cpu baseline: first step {warm:.1f} s")
     n = max(0, min(3, int(seconds_budget / max(warm, 1e-3)) - 1))
     if n == 0:
         dt, n = warm, 1       # a single step already uses the budget: report it
@@ -225,9 +242,14 @@ def main():
     D = n_tok * tok_dim
 
     model = ConditionalConvFlow(D, wl["cond"], wl["blocks"], wl["latent"], dtype=dtype)
+    log(f"rank {rank}: init {args.workload} D={D} ...")
     params = model.init(seed=42, device=device)          # same weights on every rank
     n_params = sum(p.numel() for p in params.values())
+    torch.cuda.synchronize()
+    log(f"params {n_params / 1e9:.2f} B initialised; mem {torch.cuda.memory_allocated() / 2**30:.1f} GiB")
     state = TrainState.create(apply_fn=model.apply, params=params, tx=adamw(1e-4, 1e-4), model=model)
+    torch.cuda.synchronize()
+    log(f"train state ready; mem {torch.cuda.memory_allocated() / 2**30:.1f} GiB")
     strat = ImprovedMeanFlowLoss(LinearNoiseSchedule(0.001, 0.999), MeanFlowTimeSampling(-0.4, 1.0, 0.5), True)
     reducer = GradReducer() if world > 1 else None
     g = torch.Generator(device=device).manual_seed(42 + rank)
@@ -245,8 +267,10 @@ def main():
         torch.cuda.synchronize()
 
     losses = []
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         state, loss, key = one_step(state, key)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done; peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     barrier()
     _lib.enable_timing()
     t0 = time.perf_counter()
@@ -255,6 +279,7 @@ def main():
         losses.append(loss)
     barrier()
     elapsed = time.perf_counter() - t0
+    log(f"{args.steps} timed steps in {elapsed:.3f} s")
     records = _lib.disable_timing()
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -319,12 +344,15 @@ def main():
             out["decode_ms_per_batch"] = round(dsec * 1e3, 3)
             out["decode_batch_per_gpu"] = Bd
             out["decode_finite"] = bool(torch.isfinite(audio).all().item())
+            log(f"decode {dsec * 1e3:.2f} ms per batch of {Bd}")
         except Exception as ex:  # report, never hide
             out["decode_error"] = repr(ex)[:300]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
+            log("cpu baseline (oracle on host cores) ...")
             out["cpu_baseline"] = cpu_baseline(wl)
+            log("cpu baseline done")
         except Exception as ex:
             out["cpu_baseline"] = {"error": repr(ex)[:300]}
     if rank == 0:
