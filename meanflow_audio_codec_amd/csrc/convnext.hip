@@ -11,14 +11,17 @@
 // wave owns 4 tile rows of 16 pixels = one MFMA M-tile.  Every per-pixel
 // contraction is an MFMA "K16 step" (mfc_common.h): the 3x3 conv is 9 steps
 // (one per tap, K = 16 input channels read straight out of the LDS halo
-// tile), the 1x1 convs 1-2 steps.  MFMA results (C layout: channel on the
-// lane, 4 pixels in registers) are transposed through a small wave-private LDS
-// scratch into the A layout (pixel on the lane, 4 channels in registers),
-// where channel reductions are 2 cross-lane steps and global I/O is a
-// contiguous 1 KiB per wave instruction.  Weight gradients contract over
-// pixels, for which C-layout registers ARE the MFMA operands (no movement).
-// The 32-channel intermediates never touch HBM; GRN's global statistic makes
-// the chain run twice (stats pass / apply pass), forward and backward.
+// tile), the 1x1 convs 1-2 steps.  Every product is issued TRANSPOSED,
+// Y^T = W^T X^T (weights as the A operand, pixels as the B operand), so the
+// result has the pixel on the lane and 4 output channels (4q..4q+3) in
+// registers -- exactly the B-operand layout of the next product: the whole
+// chain conv -> LN -> 1x1 -> GELU -> GRN -> 1x1 runs register-to-register with
+// no LDS round trip, channel reductions (LayerNorm) are 2 cross-lane steps
+// and global I/O is a contiguous 1 KiB per wave instruction.  Only the weight
+// gradients (contractions over pixels) need one batched transpose through a
+// wave-private LDS scratch per tile row.  The 32-channel intermediates never
+// touch HBM; GRN's global statistic makes the chain run twice (stats pass /
+// apply pass), forward and backward.
 //
 // Workgroups are persistent over a contiguous range of tiles so weight-gradient
 // and per-row statistics accumulate in registers and are flushed with a few
@@ -30,7 +33,6 @@ namespace {
 constexpr int TW = 16, TH = 16, HW = TW + 2, HH = TH + 2, NHALO = HW * HH;
 constexpr int NT = 256, NWAVES = 4, RPW = TH / NWAVES;
 constexpr int CS = 20;  // element stride of a 16-channel pixel row in LDS
-constexpr int ES = 36;  // float stride of a 32-channel pixel row in LDS scratch
 constexpr float LN_EPS = 1e-6f;
 constexpr float GRN_EPS = 1e-6f;
 
@@ -45,10 +47,19 @@ struct DevG {
 
 __device__ inline void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-__device__ inline float red_q(float v) {  // sum over the 4 lanes sharing (lane & 15)
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+// sum over the 4 lanes sharing (lane & 15): lanes 16 and 32 apart.  gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange 16-lane rows / 32-lane halves
+// in one VALU instruction (no LDS round trip as ds_bpermute would need).
+__device__ inline float red_q(float v) {
+    // inline asm: with the builtin and identical operands hipcc (ROCm 7.2) folds the two results
+    // into one register.  "s_nop 1" = the 2 wait states a VALU-written operand needs before
+    // v_permlane*_swap reads it (cdna_hip_programming.md T21).
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a: rows 0,0,2,2  b: rows 1,1,3,3
+    v = a + b;
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a: lo,lo  b: hi,hi
+    return a + b;
 }
 __device__ inline float red_m(float v) {  // sum over the 16 lanes sharing (lane >> 4)
     v += __shfl_xor(v, 1);
@@ -72,8 +83,9 @@ __device__ inline void st4(float* p, const float v[4]) {
     *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
 }
 __device__ inline void st4(u16* p, const float v[4]) {
-    *reinterpret_cast<s16x4*>(p) = s16x4{(short)f32_to_bf16(v[0]), (short)f32_to_bf16(v[1]),
-                                         (short)f32_to_bf16(v[2]), (short)f32_to_bf16(v[3])};
+    s16x4 f;
+    make_frag(f, v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<s16x4*>(p) = f;
 }
 template <typename T> __device__ inline void ld16(const T* p, float v[16]) {
 #pragma unroll
@@ -148,46 +160,75 @@ inline Geo make_geo(int64_t R, int s, int64_t maxBlocks, int64_t& grid) {
 template <typename T> struct Lds {
     T* h2s;      // [NHALO][CS]  h2 halo tile (zero outside the image)
     T* aux;      // [NHALO][CS]  tangent halo (fwd JVP) or dc1 halo (bwd conv)
-    float* x16a; // per wave [16][CS]
-    float* x16b; // per wave [16][CS]
-    float* x32a; // per wave [16][ES]
-    float* x32b; // per wave [16][ES]
-    float* st;   // per wave [2][16]   mu1, rho1 of the current tile row
+    T* ws;       // per wave [6][16][CS]  weight-gradient transpose scratch (bwd main only)
     float* fsc;  // [4][16] scale, shift, scaledot, shiftdot of the current row r
 };
+constexpr int WS_TILES = 6;
 template <typename T>
-__host__ __device__ inline size_t lds_bytes(bool aux) {
+__host__ __device__ inline size_t lds_bytes(bool aux, bool ws) {
     size_t b = (size_t)NHALO * CS * sizeof(T) * (aux ? 2 : 1);
+    if (ws) b += (size_t)NWAVES * WS_TILES * 16 * CS * sizeof(T);
     b = (b + 15) & ~(size_t)15;
-    b += NWAVES * (2 * 16 * CS + 2 * 16 * ES + 32) * sizeof(float) + 64 * sizeof(float);
-    return b;
+    return b + 64 * sizeof(float);
 }
 template <typename T>
-__device__ inline Lds<T> carve(unsigned char* base, bool aux, int wave) {
+__device__ inline Lds<T> carve(unsigned char* base, bool aux, bool ws, int wave) {
     Lds<T> l;
     l.h2s = (T*)base;
     l.aux = l.h2s + NHALO * CS;
+    T* w0 = l.h2s + (size_t)NHALO * CS * (aux ? 2 : 1);
+    l.ws = w0 + (size_t)wave * WS_TILES * 16 * CS;
     size_t b = (size_t)NHALO * CS * sizeof(T) * (aux ? 2 : 1);
+    if (ws) b += (size_t)NWAVES * WS_TILES * 16 * CS * sizeof(T);
     b = (b + 15) & ~(size_t)15;
-    float* f = (float*)(base + b);
-    float* w = f + wave * (2 * 16 * CS + 2 * 16 * ES + 32);
-    l.x16a = w; l.x16b = w + 16 * CS; l.x32a = w + 2 * 16 * CS; l.x32b = l.x32a + 16 * ES;
-    l.st = l.x32b + 16 * ES;
-    l.fsc = f + NWAVES * (2 * 16 * CS + 2 * 16 * ES + 32);
+    l.fsc = (float*)(base + b);
     return l;
 }
 
-// Stage the (TH+2)x(TW+2) halo of h2 = FiLM(LN(h0)) (and its tangent) into LDS.
+// Halo staging, split so the global loads of tile t+1 fly while tile t computes:
+//   halo_load   : raw h0 (and tangent) of the (TH+2)x(TW+2) halo -> registers (thread-per-pixel)
+//   halo_commit : h2 = FiLM(LN(h0)) (and its tangent) -> LDS, zero outside the image
+__device__ inline void unfrag(const f32x4& f, float v[4]) { v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3]; }
+__device__ inline void unfrag(const s16x4& f, float v[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = bf16_to_f32((u16)f[i]);
+}
+constexpr int HPT = (NHALO + NT - 1) / NT;  // halo pixels per thread (2)
+template <typename T, bool JVP> struct HaloRaw {
+    typename Frag<T>::type v[HPT][4], vd[JVP ? HPT : 1][4];
+    unsigned ok;
+};
 template <typename T, bool JVP>
-__device__ inline void stage_h2(const Lds<T>& l, const T* h0, const T* h0d, int64_t r, int s, int y0, int x0) {
-    for (int hp = threadIdx.x; hp < NHALO; hp += NT) {
+__device__ inline void halo_load(HaloRaw<T, JVP>& h, const T* src, const T* srcd, int64_t r, int s, int y0, int x0) {
+    typedef typename Frag<T>::type frag_t;
+    h.ok = 0;
+#pragma unroll
+    for (int k = 0; k < HPT; ++k) {
+        const int hp = threadIdx.x + k * NT;
         const int hy = hp / HW, hx = hp - hy * HW;
         const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-        float h2[16], h2d[16];
-        if (gy >= 0 && gy < s && gx >= 0 && gx < s) {
+        if (hp < NHALO && gy >= 0 && gy < s && gx >= 0 && gx < s) {
+            h.ok |= 1u << k;
             const int64_t off = ((r * s + gy) * (int64_t)s + gx) * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                h.v[k][i] = *reinterpret_cast<const frag_t*>(src + off + 4 * i);
+                if constexpr (JVP) h.vd[k][i] = *reinterpret_cast<const frag_t*>(srcd + off + 4 * i);
+            }
+        }
+    }
+}
+template <typename T, bool JVP>
+__device__ inline void halo_commit(const Lds<T>& l, const HaloRaw<T, JVP>& h) {
+#pragma unroll
+    for (int k = 0; k < HPT; ++k) {
+        const int hp = threadIdx.x + k * NT;
+        if (hp >= NHALO) continue;
+        float h2[16], h2d[16];
+        if (h.ok & (1u << k)) {
             float v[16];
-            ld16<T>(h0 + off, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) unfrag(h.v[k][i], v + 4 * i);
             float sum = 0.f, sq = 0.f;
 #pragma unroll
             for (int c = 0; c < 16; ++c) { sum += v[c]; sq += v[c] * v[c]; }
@@ -201,7 +242,8 @@ __device__ inline void stage_h2(const Lds<T>& l, const T* h0, const T* h0d, int6
             }
             if constexpr (JVP) {
                 float vd[16];
-                ld16<T>(h0d + off, vd);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) unfrag(h.vd[k][i], vd + 4 * i);
                 float sd = 0.f;
 #pragma unroll
                 for (int c = 0; c < 16; ++c) sd += vd[c];
@@ -224,41 +266,75 @@ __device__ inline void stage_h2(const Lds<T>& l, const T* h0, const T* h0d, int6
         if constexpr (JVP) st16_lds<T>(l.aux + hp * CS, h2d);
     }
 }
+// plain copy of a halo (dc1) into the aux tile, zero outside the image
+template <typename T>
+__device__ inline void halo_commit_raw(T* dst, const HaloRaw<T, false>& h) {
+    typedef typename Frag<T>::type frag_t;
+#pragma unroll
+    for (int k = 0; k < HPT; ++k) {
+        const int hp = threadIdx.x + k * NT;
+        if (hp >= NHALO) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            frag_t z;
+            frag_raw(z, (T)0, (T)0, (T)0, (T)0);
+            *reinterpret_cast<frag_t*>(dst + hp * CS + 4 * i) = (h.ok & (1u << k)) ? h.v[k][i] : z;
+        }
+    }
+}
+struct TileCoord { int64_t r; int y0, x0; };
+__device__ inline TileCoord tile_coord(const Geo& g, int64_t t) {
+    TileCoord c;
+    c.r = t / g.tilesPerImg;
+    const int ti = (int)(t - c.r * g.tilesPerImg);
+    c.y0 = (ti / g.tilesX) * TH;
+    c.x0 = (ti % g.tilesX) * TW;
+    return c;
+}
 
-// Per-lane weights / constants of the forward chain.
+// Per-lane weights / constants of the forward chain.  Lane (q, m): m = pixel
+// within the tile row, channel constants are those of channels 4q..4q+3.
 template <typename T> struct FwdW {
     typedef typename Frag<T>::type frag_t;
     frag_t wc[9], we[2], wp[2];
-    float bc, be[2], bp, lsn, gam[2], bet[2];
-    __device__ inline void load(const Dev& d, int q, int n) {
+    float bc[4], be[2][4], bp[4], ls[4], gam[2][4], bet[2][4];
+    __device__ inline void load(const Dev& d, int q, int m) {
         const T* cw = (const T*)d.conv_w;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wc[t] = load_bfrag<T>(cw + t * 256, 16, 1, 0, 0, q, n);
+        for (int t = 0; t < 9; ++t) wc[t] = load_bfrag<T>(cw + t * 256, 16, 1, 0, 0, q, m);
         const T* ew = (const T*)d.exp_w;  // [16][32]
-        we[0] = load_bfrag<T>(ew, 32, 1, 0, 0, q, n);
-        we[1] = load_bfrag<T>(ew, 32, 1, 0, 16, q, n);
+        we[0] = load_bfrag<T>(ew, 32, 1, 0, 0, q, m);
+        we[1] = load_bfrag<T>(ew, 32, 1, 0, 16, q, m);
         const T* pw = (const T*)d.con_w;  // [32][16]
-        wp[0] = load_bfrag<T>(pw, 16, 1, 0, 0, q, n);
-        wp[1] = load_bfrag<T>(pw, 16, 1, 16, 0, q, n);
-        bc = d.conv_b[n]; be[0] = d.exp_b[n]; be[1] = d.exp_b[16 + n]; bp = d.con_b[n]; lsn = d.ls[n];
-        gam[0] = d.gamma[n]; gam[1] = d.gamma[16 + n]; bet[0] = d.beta[n]; bet[1] = d.beta[16 + n];
+        wp[0] = load_bfrag<T>(pw, 16, 1, 0, 0, q, m);
+        wp[1] = load_bfrag<T>(pw, 16, 1, 16, 0, q, m);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bc[i] = d.conv_b[4 * q + i]; bp[i] = d.con_b[4 * q + i]; ls[i] = d.ls[4 * q + i];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                be[j][i] = d.exp_b[16 * j + 4 * q + i];
+                gam[j][i] = d.gamma[16 * j + 4 * q + i];
+                bet[j][i] = d.beta[16 * j + 4 * q + i];
+            }
+        }
     }
 };
 
-// Result of the chain up to gelu for one tile row (16 pixels).
+// Result of the chain up to gelu for one tile row (16 pixels), all in the
+// pixel-on-lane layout: element i of a vector = channel 4q+i (e/g: 16j+4q+i).
 template <typename T, bool JVP> struct RowFwd {
     typedef typename Frag<T>::type frag_t;
-    f32x4 c1;            // conv output (C layout)
-    float n1[4];         // LN(c1), A layout (pixel = lane&15, channels 4q..4q+3)
+    float n1[4];         // LN(c1)
     float rho1;
     frag_t n1f, n1df;
-    f32x4 e[2], ed[2], g[2], gd[2];
+    f32x4 g[2], gp[2], gd[2];   // gelu(e), gelu'(e) (when WG), tangent of g (when JVP)
 };
 
-template <typename T, bool JVP>
+template <typename T, bool JVP, bool WG>
 __device__ inline void chain_row(const Lds<T>& l, const FwdW<T>& w, int y, int q, int m, RowFwd<T, JVP>& o) {
     typedef typename Frag<T>::type frag_t;
-    f32x4 acc = f32x4{w.bc, w.bc, w.bc, w.bc};
+    f32x4 acc = f32x4{w.bc[0], w.bc[1], w.bc[2], w.bc[3]};
     f32x4 accd = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
@@ -266,45 +342,34 @@ __device__ inline void chain_row(const Lds<T>& l, const FwdW<T>& w, int y, int q
         for (int dx = 0; dx < 3; ++dx) {
             const int off = ((y + dy) * HW + (m + dx)) * CS + 4 * q;
             const frag_t a = *reinterpret_cast<const frag_t*>(l.h2s + off);
-            mma16(acc, a, w.wc[dy * 3 + dx]);
+            mma16(acc, w.wc[dy * 3 + dx], a);      // c1^T = Wc^T h2^T
             if constexpr (JVP) {
                 const frag_t ad = *reinterpret_cast<const frag_t*>(l.aux + off);
-                mma16(accd, ad, w.wc[dy * 3 + dx]);
+                mma16(accd, w.wc[dy * 3 + dx], ad);
             }
         }
-    o.c1 = acc;
-    // C layout -> scratch [pixel][channel]
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        l.x16a[(4 * q + e) * CS + m] = acc[e];
-        if constexpr (JVP) l.x16b[(4 * q + e) * CS + m] = accd[e];
-    }
-    lds_fence();
-    float v[4], mean;
-    ld4(l.x16a + m * CS + 4 * q, v);
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]}, mean;
     ln_fwd_a(v, o.n1, mean, o.rho1);
     make_frag(o.n1f, o.n1[0], o.n1[1], o.n1[2], o.n1[3]);
-    if (q == 0) { l.st[m] = mean; l.st[16 + m] = o.rho1; }
     if constexpr (JVP) {
-        float vd[4], nd[4];
-        ld4(l.x16b + m * CS + 4 * q, vd);
+        float vd[4] = {accd[0], accd[1], accd[2], accd[3]}, nd[4];
         ln_jvp_a(vd, o.n1, o.rho1, nd);
         make_frag(o.n1df, nd[0], nd[1], nd[2], nd[3]);
     }
-    lds_fence();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        f32x4 e = f32x4{w.be[j], w.be[j], w.be[j], w.be[j]};
-        mma16(e, o.n1f, w.we[j]);
-        o.e[j] = e;
+        f32x4 e = f32x4{w.be[j][0], w.be[j][1], w.be[j][2], w.be[j][3]};
+        mma16(e, w.we[j], o.n1f);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o.g[j][i] = gelu_f(e[i]);
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (WG || JVP) { float gv, gpv; gelu_both(e[i], gv, gpv); o.g[j][i] = gv; o.gp[j][i] = gpv; }
+            else o.g[j][i] = gelu_f(e[i]);
+        }
         if constexpr (JVP) {
             f32x4 ed = f32x4{0.f, 0.f, 0.f, 0.f};
-            mma16(ed, o.n1df, w.we[j]);
-            o.ed[j] = ed;
+            mma16(ed, w.we[j], o.n1df);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o.gd[j][i] = ed[i] * gelu_grad_f(e[i]);
+            for (int i = 0; i < 4; ++i) o.gd[j][i] = ed[i] * o.gp[j][i];
         }
     }
 }
@@ -320,13 +385,14 @@ struct FwdArgs {
 };
 
 template <typename T, bool JVP>
-__device__ inline void load_film(const Lds<T>& l, const FwdArgs& a, int64_t r) {
+__device__ inline void load_film(const Lds<T>& l, const float* sc, const float* sh, const float* scd,
+                                 const float* shd, int64_t r) {
     if (threadIdx.x < 16) {
-        l.fsc[threadIdx.x] = a.sc[r * 16 + threadIdx.x];
-        l.fsc[16 + threadIdx.x] = a.sh[r * 16 + threadIdx.x];
+        l.fsc[threadIdx.x] = sc[r * 16 + threadIdx.x];
+        l.fsc[16 + threadIdx.x] = sh[r * 16 + threadIdx.x];
         if constexpr (JVP) {
-            l.fsc[32 + threadIdx.x] = a.scd[r * 16 + threadIdx.x];
-            l.fsc[48 + threadIdx.x] = a.shd[r * 16 + threadIdx.x];
+            l.fsc[32 + threadIdx.x] = scd[r * 16 + threadIdx.x];
+            l.fsc[48 + threadIdx.x] = shd[r * 16 + threadIdx.x];
         }
     }
 }
@@ -339,7 +405,7 @@ cnx_fwd_kernel(FwdArgs a) {
     typedef typename Frag<T>::type frag_t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, m = lane & 15;
-    Lds<T> l = carve<T>(smem, JVP, wave);
+    Lds<T> l = carve<T>(smem, JVP, false, wave);
     FwdW<T> w;
     w.load(a.p, q, m);
     const int s = a.geo.s;
@@ -349,107 +415,103 @@ cnx_fwd_kernel(FwdArgs a) {
     int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
     int64_t t1 = t0 + a.geo.chunk < a.geo.total ? t0 + a.geo.chunk : a.geo.total;
     int64_t rcur = -1;
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-    float qv[2] = {0.f, 0.f}, qdv[2] = {0.f, 0.f};
+    float s1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, s2[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float qv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, qdv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
     auto flush_stats = [&](int64_t r) {
         if constexpr (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float v1 = red_q(s1[j]);
-                if (q == 0) atomicAdd(a.S1 + r * 32 + 16 * j + m, v1);
-                if constexpr (JVP) {
-                    const float v2 = red_q(s2[j]);
-                    if (q == 0) atomicAdd(a.S2 + r * 32 + 16 * j + m, v2);
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v1 = red_m(s1[j][i]);
+                    if (m == 0) atomicAdd(a.S1 + r * 32 + 16 * j + 4 * q + i, v1);
+                    if constexpr (JVP) {
+                        const float v2 = red_m(s2[j][i]);
+                        if (m == 0) atomicAdd(a.S2 + r * 32 + 16 * j + 4 * q + i, v2);
+                    }
+                    s1[j][i] = 0.f; s2[j][i] = 0.f;
                 }
-                s1[j] = 0.f; s2[j] = 0.f;
-            }
         }
     };
 
+    HaloRaw<T, JVP> raw;
+    if (t0 < t1) { const TileCoord c = tile_coord(a.geo, t0); halo_load<T, JVP>(raw, h0, h0d, c.r, s, c.y0, c.x0); }
     for (int64_t t = t0; t < t1; ++t) {
-        const int64_t r = t / a.geo.tilesPerImg;
-        const int ti = (int)(t - r * a.geo.tilesPerImg);
-        const int y0 = (ti / a.geo.tilesX) * TH, x0 = (ti % a.geo.tilesX) * TW;
+        const TileCoord tc = tile_coord(a.geo, t);
+        const int64_t r = tc.r;
+        const int y0 = tc.y0, x0 = tc.x0;
         __syncthreads();  // previous tile fully consumed
         if (r != rcur) {
             if (rcur >= 0) flush_stats(rcur);
             rcur = r;
-            load_film<T, JVP>(l, a, r);
+            load_film<T, JVP>(l, a.sc, a.sh, a.scd, a.shd, r);
             if constexpr (MODE == 1) {
-                qv[0] = a.q[r * 32 + m]; qv[1] = a.q[r * 32 + 16 + m];
-                if constexpr (JVP) { qdv[0] = a.qd[r * 32 + m]; qdv[1] = a.qd[r * 32 + 16 + m]; }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        qv[j][i] = a.q[r * 32 + 16 * j + 4 * q + i];
+                        if constexpr (JVP) qdv[j][i] = a.qd[r * 32 + 16 * j + 4 * q + i];
+                    }
             }
             __syncthreads();
         }
-        stage_h2<T, JVP>(l, h0, h0d, r, s, y0, x0);
+        halo_commit<T, JVP>(l, raw);
         __syncthreads();
+        if (t + 1 < t1) { const TileCoord c = tile_coord(a.geo, t + 1); halo_load<T, JVP>(raw, h0, h0d, c.r, s, c.y0, c.x0); }
+        const int gx = x0 + m;
 #pragma unroll 1
         for (int ri = 0; ri < RPW; ++ri) {
             const int y = wave * RPW + ri;
             const int gy = y0 + y;
+            const bool ok = gy < s && gx < s;
             RowFwd<T, JVP> f;
-            chain_row<T, JVP>(l, w, y, q, m, f);
+            chain_row<T, JVP, false>(l, w, y, q, m, f);
             if constexpr (MODE == 0) {
+                if (ok) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool ok = gy < s && (x0 + 4 * q + e) < s;
-                    if (ok) {
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            s1[j] += f.g[j][e] * f.g[j][e];
-                            if constexpr (JVP) s2[j] += f.g[j][e] * f.gd[j][e];
+                        for (int i = 0; i < 4; ++i) {
+                            s1[j][i] += f.g[j][i] * f.g[j][i];
+                            if constexpr (JVP) s2[j][i] += f.g[j][i] * f.gd[j][i];
                         }
-                    }
                 }
             } else {
-                // GRN apply (C layout, channel constants on the lane)
+                f32x4 p1 = f32x4{w.bp[0], w.bp[1], w.bp[2], w.bp[3]}, p1d = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float yv = f.g[j][e] * (w.gam[j] + qv[j]) + w.bet[j];
-                        l.x32a[(4 * q + e) * ES + 16 * j + m] = yv;
-                        if constexpr (JVP) {
-                            const float yd = f.gd[j][e] * (w.gam[j] + qv[j]) + f.g[j][e] * qdv[j];
-                            l.x32b[(4 * q + e) * ES + 16 * j + m] = yd;
-                        }
-                    }
-                lds_fence();
-                f32x4 p1 = f32x4{w.bp, w.bp, w.bp, w.bp}, p1d = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    float yv[4];
-                    ld4(l.x32a + m * ES + 16 * c + 4 * q, yv);
+                for (int j = 0; j < 2; ++j) {
                     frag_t yf;
-                    make_frag(yf, yv[0], yv[1], yv[2], yv[3]);
-                    mma16(p1, yf, w.wp[c]);
+                    make_frag(yf, f.g[j][0] * (w.gam[j][0] + qv[j][0]) + w.bet[j][0],
+                              f.g[j][1] * (w.gam[j][1] + qv[j][1]) + w.bet[j][1],
+                              f.g[j][2] * (w.gam[j][2] + qv[j][2]) + w.bet[j][2],
+                              f.g[j][3] * (w.gam[j][3] + qv[j][3]) + w.bet[j][3]);
+                    mma16(p1, w.wp[j], yf);
                     if constexpr (JVP) {
-                        ld4(l.x32b + m * ES + 16 * c + 4 * q, yv);
-                        make_frag(yf, yv[0], yv[1], yv[2], yv[3]);
-                        mma16(p1d, yf, w.wp[c]);
+                        frag_t ydf;
+                        make_frag(ydf, f.gd[j][0] * (w.gam[j][0] + qv[j][0]) + f.g[j][0] * qdv[j][0],
+                                  f.gd[j][1] * (w.gam[j][1] + qv[j][1]) + f.g[j][1] * qdv[j][1],
+                                  f.gd[j][2] * (w.gam[j][2] + qv[j][2]) + f.g[j][2] * qdv[j][2],
+                                  f.gd[j][3] * (w.gam[j][3] + qv[j][3]) + f.g[j][3] * qdv[j][3]);
+                        mma16(p1d, w.wp[j], ydf);
                     }
                 }
-                // layer scale + residual (h2 from the halo tile centre), back to A layout
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int hoff = ((y + 1) * HW + (4 * q + e + 1)) * CS + m;
-                    l.x16a[(4 * q + e) * CS + m] = p1[e] * w.lsn + St<T>::ld(l.h2s + hoff);
-                    if constexpr (JVP) l.x16b[(4 * q + e) * CS + m] = p1d[e] * w.lsn + St<T>::ld(l.aux + hoff);
-                }
-                lds_fence();
-                const int gx = x0 + m;
-                if (gy < s && gx < s) {
+                if (ok) {
+                    const int hoff = ((y + 1) * HW + (m + 1)) * CS + 4 * q;
                     const int64_t off = ((r * s + gy) * (int64_t)s + gx) * 16 + 4 * q;
-                    float ov[4];
-                    ld4(l.x16a + m * CS + 4 * q, ov);
+                    float res[4], ov[4];
+                    ld4(l.h2s + hoff, res);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ov[i] = p1[i] * w.ls[i] + res[i];
                     st4((T*)a.o + off, ov);
                     if constexpr (JVP) {
-                        ld4(l.x16b + m * CS + 4 * q, ov);
+                        ld4(l.aux + hoff, res);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ov[i] = p1d[i] * w.ls[i] + res[i];
                         st4((T*)a.od + off, ov);
                     }
                 }
-                lds_fence();
             }
         }
     }
@@ -468,6 +530,16 @@ struct BwdArgs {
     float* dq; void* dc1; void* dh0; float* dsc; float* dsh;
 };
 
+// read a [16 pixel][CS] scratch tile as an operand that has the PIXEL as k:
+// lane (q, r): elements (pixel 4q+i, channel r)
+template <typename T>
+__device__ inline typename Frag<T>::type pix_k_frag(const T* tile, int q, int r) {
+    typename Frag<T>::type f;
+    const T* p = tile + (4 * q) * CS + r;
+    frag_raw(f, p[0], p[CS], p[2 * CS], p[3 * CS]);
+    return f;
+}
+
 // MODE 0: dq[r,ch] = sum dy*g1, dbeta += sum dy.
 // MODE 1: dc1 + small-parameter gradients (con_w, con_b, ls, exp_w, exp_b, conv_b).
 template <typename T, int MODE>
@@ -477,168 +549,166 @@ cnx_bwd_kernel(BwdArgs a) {
     typedef typename Frag<T>::type frag_t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, m = lane & 15;
-    Lds<T> l = carve<T>(smem, false, wave);
+    Lds<T> l = carve<T>(smem, false, MODE == 1, wave);
     FwdW<T> w;
     w.load(a.p, q, m);
-    // transposed 1x1 weights as B operands
-    const T* pw = (const T*)a.p.con_w;  // [32][16]: dy[e] = sum_c dp1[c] Wp[e][c]
+    // transposed 1x1 weights (A operands of the transposed products)
+    const T* pw = (const T*)a.p.con_w;  // [32][16]: dy[e] = sum_c Wp[e][c] dp1[c]
     frag_t wpT[2] = {load_bfrag<T>(pw, 1, 16, 0, 0, q, m), load_bfrag<T>(pw, 1, 16, 0, 16, q, m)};
-    const T* ew = (const T*)a.p.exp_w;  // [16][32]: dn1[c] = sum_e de[e] We[c][e]
+    const T* ew = (const T*)a.p.exp_w;  // [16][32]: dn1[c] = sum_e We[c][e] de[e]
     frag_t weT[2] = {load_bfrag<T>(ew, 1, 32, 0, 0, q, m), load_bfrag<T>(ew, 1, 32, 16, 0, q, m)};
-    float ls4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ls4[i] = a.p.ls[4 * q + i];
     const int s = a.geo.s;
     const T* h0 = (const T*)a.h0;
     const T* dout = (const T*)a.dout;
 
-    FwdArgs fa;  // only the FiLM pointers are used by load_film
-    fa.sc = a.sc; fa.sh = a.sh; fa.scd = nullptr; fa.shd = nullptr;
-
     int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
     int64_t t1 = t0 + a.geo.chunk < a.geo.total ? t0 + a.geo.chunk : a.geo.total;
     int64_t rcur = -1;
-    float qv[2] = {0.f, 0.f}, kg[2] = {0.f, 0.f};
-    float dqp[2] = {0.f, 0.f}, dbeta[2] = {0.f, 0.f};
+    float qv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, kg[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float dqp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dbeta[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     // MODE 1 accumulators
     f32x4 aWp[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, aWe[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-    float dls = 0.f, dbp = 0.f, dbe[2] = {0.f, 0.f}, dbc[4] = {0.f, 0.f, 0.f, 0.f};
+    float dls[4] = {0.f, 0.f, 0.f, 0.f}, dbp[4] = {0.f, 0.f, 0.f, 0.f}, dbc[4] = {0.f, 0.f, 0.f, 0.f};
+    float dbe[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
     auto flush_row = [&](int64_t r) {
         if constexpr (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float v = red_q(dqp[j]);
-                if (q == 0) atomicAdd(a.dq + r * 32 + 16 * j + m, v);
-                dqp[j] = 0.f;
-            }
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = red_m(dqp[j][i]);
+                    if (m == 0) atomicAdd(a.dq + r * 32 + 16 * j + 4 * q + i, v);
+                    dqp[j][i] = 0.f;
+                }
         }
     };
 
+    // dout of this wave's 4 tile rows, fetched one tile ahead
+    auto load_dout = [&](frag_t d[RPW], const TileCoord& c) {
+#pragma unroll
+        for (int ri = 0; ri < RPW; ++ri) {
+            const int gy = c.y0 + wave * RPW + ri, gxx = c.x0 + m;
+            if (gy < s && gxx < s) d[ri] = *reinterpret_cast<const frag_t*>(dout + ((c.r * s + gy) * (int64_t)s + gxx) * 16 + 4 * q);
+            else frag_raw(d[ri], (T)0, (T)0, (T)0, (T)0);
+        }
+    };
+    HaloRaw<T, false> raw;
+    frag_t dnext[RPW];
+    if (t0 < t1) {
+        const TileCoord c = tile_coord(a.geo, t0);
+        halo_load<T, false>(raw, h0, nullptr, c.r, s, c.y0, c.x0);
+        load_dout(dnext, c);
+    }
     for (int64_t t = t0; t < t1; ++t) {
-        const int64_t r = t / a.geo.tilesPerImg;
-        const int ti = (int)(t - r * a.geo.tilesPerImg);
-        const int y0 = (ti / a.geo.tilesX) * TH, x0 = (ti % a.geo.tilesX) * TW;
+        const TileCoord tc = tile_coord(a.geo, t);
+        const int64_t r = tc.r;
+        const int y0 = tc.y0, x0 = tc.x0;
+        const int gx = x0 + m;
         __syncthreads();
+        frag_t dcur[RPW];
+#pragma unroll
+        for (int ri = 0; ri < RPW; ++ri) dcur[ri] = dnext[ri];
         if (r != rcur) {
             if (rcur >= 0) flush_row(rcur);
             rcur = r;
-            load_film<T, false>(l, fa, r);
-            qv[0] = a.q[r * 32 + m]; qv[1] = a.q[r * 32 + 16 + m];
-            if constexpr (MODE == 1) { kg[0] = a.kG[r * 32 + m]; kg[1] = a.kG[r * 32 + 16 + m]; }
+            load_film<T, false>(l, a.sc, a.sh, nullptr, nullptr, r);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    qv[j][i] = a.q[r * 32 + 16 * j + 4 * q + i];
+                    if constexpr (MODE == 1) kg[j][i] = a.kG[r * 32 + 16 * j + 4 * q + i];
+                }
             __syncthreads();
         }
-        stage_h2<T, false>(l, h0, nullptr, r, s, y0, x0);
+        halo_commit<T, false>(l, raw);
         __syncthreads();
+        if (t + 1 < t1) {
+            const TileCoord c = tile_coord(a.geo, t + 1);
+            halo_load<T, false>(raw, h0, nullptr, c.r, s, c.y0, c.x0);
+            load_dout(dnext, c);
+        }
 #pragma unroll 1
         for (int ri = 0; ri < RPW; ++ri) {
             const int y = wave * RPW + ri;
-            const int gy = y0 + y, gx = x0 + m;
+            const int gy = y0 + y;
+            const bool ok = gy < s && gx < s;
+            float dov[4];
+            unfrag(dcur[0], dov);
+#pragma unroll
+            for (int k = 0; k + 1 < RPW; ++k) dcur[k] = dcur[k + 1];   // rotate: static register indices
             RowFwd<T, false> f;
-            chain_row<T, false>(l, w, y, q, m, f);
-            // dout for this tile row, A layout (zero outside the image)
-            float dov[4] = {0.f, 0.f, 0.f, 0.f};
-            const int64_t goff = ((r * s + gy) * (int64_t)s + gx) * 16 + 4 * q;
-            if (gy < s && gx < s) ld4(dout + goff, dov);
+            chain_row<T, false, MODE == 1>(l, w, y, q, m, f);
+            float dp1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dp1[i] = dov[i] * w.ls[i];
             frag_t dp1f;
-            make_frag(dp1f, dov[0] * ls4[0], dov[1] * ls4[1], dov[2] * ls4[2], dov[3] * ls4[3]);
+            make_frag(dp1f, dp1[0], dp1[1], dp1[2], dp1[3]);
             f32x4 dy[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 dy[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                mma16(dy[j], dp1f, wpT[j]);
+                mma16(dy[j], wpT[j], dp1f);      // dy^T = Wp dp1^T
             }
             if constexpr (MODE == 0) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { dqp[j] += dy[j][e] * f.g[j][e]; dbeta[j] += dy[j][e]; }
+                    for (int i = 0; i < 4; ++i) { dqp[j][i] += dy[j][i] * f.g[j][i]; dbeta[j][i] += dy[j][i]; }
             } else {
-                // ---- recompute y, p1 (needed for dW_contract and d layer_scale)
-                f32x4 yv[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        yv[j][e] = f.g[j][e] * (w.gam[j] + qv[j]) + w.bet[j];
-                        l.x32a[(4 * q + e) * ES + 16 * j + m] = yv[j][e];
-                    }
-                // dout to scratch for the C-layout view
-                st4(l.x16b + m * CS + 4 * q, dov);
-                lds_fence();
-                f32x4 p1 = f32x4{w.bp, w.bp, w.bp, w.bp};
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    float t4[4];
-                    ld4(l.x32a + m * ES + 16 * c + 4 * q, t4);
-                    frag_t yf;
-                    make_frag(yf, t4[0], t4[1], t4[2], t4[3]);
-                    mma16(p1, yf, w.wp[c]);
-                }
-                f32x4 dp1c;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d = l.x16b[(4 * q + e) * CS + m];  // dout[pixel 4q+e][channel m]
-                    dls += d * p1[e];
-                    dp1c[e] = d * w.lsn;
-                    dbp += dp1c[e];
-                }
-                lds_fence();
-                // dW_contract[e][c] += sum_pixels y[p][e] dp1[p][c]   (C-layout operands)
-                frag_t bdp;
-                frag_of(bdp, dp1c);
+                // y, p1 (needed for dW_contract and d layer_scale)
+                float yv[2][4];
+                f32x4 p1 = f32x4{w.bp[0], w.bp[1], w.bp[2], w.bp[3]};
+                frag_t yf[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    frag_t ay;
-                    frag_of(ay, yv[j]);
-                    mma16(aWp[j], ay, bdp);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) yv[j][i] = f.g[j][i] * (w.gam[j][i] + qv[j][i]) + w.bet[j][i];
+                    make_frag(yf[j], yv[j][0], yv[j][1], yv[j][2], yv[j][3]);
+                    mma16(p1, w.wp[j], yf[j]);
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { dls[i] += dov[i] * p1[i]; dbp[i] += dp1[i]; }
                 // d gelu / d expand
-                f32x4 de[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool ok = gy < s && (x0 + 4 * q + e) < s;
-                        const float dg = dy[j][e] * (w.gam[j] + qv[j]) + f.g[j][e] * kg[j];
-                        const float d = ok ? dg * gelu_grad_f(f.e[j][e]) : 0.f;
-                        de[j][e] = d;
-                        dbe[j] += d;
-                        l.x32b[(4 * q + e) * ES + 16 * j + m] = d;
-                    }
-                // dW_expand[c][e] += sum_pixels n1[p][c] de[p][e]; n1 in C layout from c1 + stats
-                f32x4 n1c;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) n1c[e] = (f.c1[e] - l.st[4 * q + e]) * l.st[16 + 4 * q + e];
-                frag_t an1;
-                frag_of(an1, n1c);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    frag_t bde;
-                    frag_of(bde, de[j]);
-                    mma16(aWe[j], an1, bde);
-                }
-                lds_fence();
-                // dn1 = de . We^T  (A operand: de in A layout via scratch)
+                frag_t def[2];
                 f32x4 dn1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    float t4[4];
-                    ld4(l.x32b + m * ES + 16 * c + 4 * q, t4);
-                    frag_t df;
-                    make_frag(df, t4[0], t4[1], t4[2], t4[3]);
-                    mma16(dn1, df, weT[c]);
-                }
+                for (int j = 0; j < 2; ++j) {
+                    float de[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) l.x16a[(4 * q + e) * CS + m] = dn1[e];
-                lds_fence();
-                float dn[4], dc[4];
-                ld4(l.x16a + m * CS + 4 * q, dn);
+                    for (int i = 0; i < 4; ++i) {
+                        const float dg = dy[j][i] * (w.gam[j][i] + qv[j][i]) + f.g[j][i] * kg[j][i];
+                        de[i] = ok ? dg * f.gp[j][i] : 0.f;
+                        dbe[j][i] += de[i];
+                    }
+                    make_frag(def[j], de[0], de[1], de[2], de[3]);
+                    mma16(dn1, weT[j], def[j]);      // dn1^T = We de^T
+                }
+                float dn[4] = {dn1[0], dn1[1], dn1[2], dn1[3]}, dc[4];
                 ln_bwd_a(dn, f.n1, f.rho1, dc);
-                if (gy < s && gx < s) {
+                if (ok) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) dbc[i] += dc[i];
-                    st4((T*)a.dc1 + goff, dc);
+                    st4((T*)a.dc1 + ((r * s + gy) * (int64_t)s + gx) * 16 + 4 * q, dc);
+                }
+                // weight gradients contract over the 16 pixels of the row: one batched transpose
+                // (pixel-on-lane -> pixel-as-k) of y0, y1, dp1, n1, de0, de1 through the wave scratch
+                *reinterpret_cast<frag_t*>(l.ws + (0 * 16 + m) * CS + 4 * q) = yf[0];
+                *reinterpret_cast<frag_t*>(l.ws + (1 * 16 + m) * CS + 4 * q) = yf[1];
+                *reinterpret_cast<frag_t*>(l.ws + (2 * 16 + m) * CS + 4 * q) = dp1f;
+                *reinterpret_cast<frag_t*>(l.ws + (3 * 16 + m) * CS + 4 * q) = f.n1f;
+                *reinterpret_cast<frag_t*>(l.ws + (4 * 16 + m) * CS + 4 * q) = def[0];
+                *reinterpret_cast<frag_t*>(l.ws + (5 * 16 + m) * CS + 4 * q) = def[1];
+                lds_fence();
+                const frag_t tdp = pix_k_frag<T>(l.ws + 2 * 16 * CS, q, m);
+                const frag_t tn1 = pix_k_frag<T>(l.ws + 3 * 16 * CS, q, m);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const frag_t ty = pix_k_frag<T>(l.ws + j * 16 * CS, q, m);
+                    const frag_t tde = pix_k_frag<T>(l.ws + (4 + j) * 16 * CS, q, m);
+                    mma16(aWp[j], ty, tdp);    // [e][c] += y^T dp1
+                    mma16(aWe[j], tn1, tde);   // [c][e] += n1^T de
                 }
                 lds_fence();
             }
@@ -647,10 +717,12 @@ cnx_bwd_kernel(BwdArgs a) {
     if (rcur >= 0) flush_row(rcur);
     if constexpr (MODE == 0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float v = red_q(dbeta[j]);
-            if (q == 0) atomicAdd(a.g.beta + 16 * j + m, v);
-        }
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = red_m(dbeta[j][i]);
+                if (m == 0) atomicAdd(a.g.beta + 16 * j + 4 * q + i, v);
+            }
     } else {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -659,17 +731,19 @@ cnx_bwd_kernel(BwdArgs a) {
                 atomicAdd(a.g.con_w + (16 * j + 4 * q + e) * 16 + m, aWp[j][e]);
                 atomicAdd(a.g.exp_w + (4 * q + e) * 32 + 16 * j + m, aWe[j][e]);
             }
-        const float v1 = red_q(dls), v2 = red_q(dbp);
-        if (q == 0) { atomicAdd(a.g.ls + m, v1); atomicAdd(a.g.con_b + m, v2); }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float v = red_q(dbe[j]);
-            if (q == 0) atomicAdd(a.g.exp_b + 16 * j + m, v);
-        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float v = red_m(dbc[i]);
-            if (m == 0) atomicAdd(a.g.conv_b + 4 * q + i, v);
+            const float v1 = red_m(dls[i]), v2 = red_m(dbp[i]), v3 = red_m(dbc[i]);
+            if (m == 0) {
+                atomicAdd(a.g.ls + 4 * q + i, v1);
+                atomicAdd(a.g.con_b + 4 * q + i, v2);
+                atomicAdd(a.g.conv_b + 4 * q + i, v3);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float v = red_m(dbe[j][i]);
+                if (m == 0) atomicAdd(a.g.exp_b + 16 * j + 4 * q + i, v);
+            }
         }
     }
 }
@@ -682,17 +756,15 @@ cnx_bwd_conv_kernel(BwdArgs a) {
     typedef typename Frag<T>::type frag_t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, m = lane & 15;
-    Lds<T> l = carve<T>(smem, true, wave);
+    Lds<T> l = carve<T>(smem, true, false, wave);
     const T* cw = (const T*)a.p.conv_w;  // [tap][ic][oc]
-    frag_t wcT[9];  // B[k=oc][col=ic]
+    frag_t wcT[9];  // A[row=ic][k=oc] of the transposed product dh2^T = Wc dc1^T
 #pragma unroll
     for (int t = 0; t < 9; ++t) wcT[t] = load_bfrag<T>(cw + t * 256, 1, 16, 0, 0, q, m);
     const int s = a.geo.s;
     const T* h0 = (const T*)a.h0;
     const T* dout = (const T*)a.dout;
     const T* dc1 = (const T*)a.dc1_in;
-    FwdArgs fa;
-    fa.sc = a.sc; fa.sh = a.sh; fa.scd = nullptr; fa.shd = nullptr;
 
     int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
     int64_t t1 = t0 + a.geo.chunk < a.geo.total ? t0 + a.geo.chunk : a.geo.total;
@@ -712,38 +784,64 @@ cnx_bwd_conv_kernel(BwdArgs a) {
         }
     };
 
+    // centre-pixel dout / h0 of this wave's rows, fetched one tile ahead
+    auto load_centre = [&](frag_t d[RPW], frag_t hh[RPW], const TileCoord& c) {
+#pragma unroll
+        for (int ri = 0; ri < RPW; ++ri) {
+            const int gy = c.y0 + wave * RPW + ri, gxx = c.x0 + m;
+            if (gy < s && gxx < s) {
+                const int64_t goff = ((c.r * s + gy) * (int64_t)s + gxx) * 16 + 4 * q;
+                d[ri] = *reinterpret_cast<const frag_t*>(dout + goff);
+                hh[ri] = *reinterpret_cast<const frag_t*>(h0 + goff);
+            } else {
+                frag_raw(d[ri], (T)0, (T)0, (T)0, (T)0);
+                frag_raw(hh[ri], (T)0, (T)0, (T)0, (T)0);
+            }
+        }
+    };
+    HaloRaw<T, false> raw, rawd;
+    frag_t dnext[RPW], hnext[RPW];
+    if (t0 < t1) {
+        const TileCoord c = tile_coord(a.geo, t0);
+        halo_load<T, false>(raw, h0, nullptr, c.r, s, c.y0, c.x0);
+        halo_load<T, false>(rawd, dc1, nullptr, c.r, s, c.y0, c.x0);
+        load_centre(dnext, hnext, c);
+    }
     for (int64_t t = t0; t < t1; ++t) {
-        const int64_t r = t / a.geo.tilesPerImg;
-        const int ti = (int)(t - r * a.geo.tilesPerImg);
-        const int y0 = (ti / a.geo.tilesX) * TH, x0 = (ti % a.geo.tilesX) * TW;
+        const TileCoord tc = tile_coord(a.geo, t);
+        const int64_t r = tc.r;
+        const int y0 = tc.y0, x0 = tc.x0;
+        const int gx = x0 + m;
         __syncthreads();
+        frag_t dcur[RPW], hcur[RPW];
+#pragma unroll
+        for (int ri = 0; ri < RPW; ++ri) { dcur[ri] = dnext[ri]; hcur[ri] = hnext[ri]; }
         if (r != rcur) {
             if (rcur >= 0) flush_row(rcur);
             rcur = r;
-            load_film<T, false>(l, fa, r);
+            load_film<T, false>(l, a.sc, a.sh, nullptr, nullptr, r);
 #pragma unroll
             for (int i = 0; i < 4; ++i) sc4[i] = a.sc[r * 16 + 4 * q + i];
             __syncthreads();
         }
-        stage_h2<T, false>(l, h0, nullptr, r, s, y0, x0);
-        // dc1 halo (zero outside the image)
-        for (int hp = threadIdx.x; hp < NHALO; hp += NT) {
-            const int hy = hp / HW, hx = hp - hy * HW;
-            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-            float v[16];
-            if (gy >= 0 && gy < s && gx >= 0 && gx < s) {
-                ld16<T>(dc1 + ((r * s + gy) * (int64_t)s + gx) * 16, v);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) v[c] = 0.f;
-            }
-            st16_lds<T>(l.aux + hp * CS, v);
-        }
+        halo_commit<T, false>(l, raw);
+        halo_commit_raw<T>(l.aux, rawd);
         __syncthreads();
+        if (t + 1 < t1) {
+            const TileCoord c = tile_coord(a.geo, t + 1);
+            halo_load<T, false>(raw, h0, nullptr, c.r, s, c.y0, c.x0);
+            halo_load<T, false>(rawd, dc1, nullptr, c.r, s, c.y0, c.x0);
+            load_centre(dnext, hnext, c);
+        }
 #pragma unroll 1
         for (int ri = 0; ri < RPW; ++ri) {
             const int y = wave * RPW + ri;
-            const int gy = y0 + y, gx = x0 + m;
+            const int gy = y0 + y;
+            float dov[4], hv[4];
+            unfrag(dcur[0], dov);
+            unfrag(hcur[0], hv);
+#pragma unroll
+            for (int k = 0; k + 1 < RPW; ++k) { dcur[k] = dcur[k + 1]; hcur[k] = hcur[k + 1]; }
             // dh2 = conv^T(dc1): h2[p] feeds c1[p - (i-1, j-1)] through K[i][j]
             f32x4 dh = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -752,39 +850,25 @@ cnx_bwd_conv_kernel(BwdArgs a) {
                 for (int j = 0; j < 3; ++j) {
                     const frag_t ad = *reinterpret_cast<const frag_t*>(
                         l.aux + ((y + 2 - i) * HW + (m + 2 - j)) * CS + 4 * q);
-                    mma16(dh, ad, wcT[i * 3 + j]);
+                    mma16(dh, wcT[i * 3 + j], ad);
                 }
             // dWc[tap][ic][oc] += sum_pixels h2[p + tap][ic] dc1[p][oc]
             {
-                const T* dcp = l.aux + ((y + 1) * HW + (4 * q + 1)) * CS + m;
-                frag_t bd;
-                frag_raw(bd, dcp[0], dcp[CS], dcp[2 * CS], dcp[3 * CS]);
+                const frag_t bd = pix_k_frag<T>(l.aux + ((y + 1) * HW + 1) * CS, q, m);
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        const T* hp = l.h2s + ((y + i) * HW + (4 * q + j)) * CS + m;
-                        frag_t ah;
-                        frag_raw(ah, hp[0], hp[CS], hp[2 * CS], hp[3 * CS]);
+                        const frag_t ah = pix_k_frag<T>(l.h2s + ((y + i) * HW + j) * CS, q, m);
                         mma16(aWc[i * 3 + j], ah, bd);
                     }
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) l.x16a[(4 * q + e) * CS + m] = dh[e];
-            lds_fence();
-            float d2[4];
-            ld4(l.x16a + m * CS + 4 * q, d2);
-            lds_fence();
             if (gy < s && gx < s) {
                 const int64_t goff = ((r * s + gy) * (int64_t)s + gx) * 16 + 4 * q;
-                float dov[4], hv[4];
-                ld4(dout + goff, dov);
-                ld4(h0 + goff, hv);
+                float d2[4], h1[4], mean, rho, dh1[4], dx[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) d2[i] += dov[i];  // residual branch o = ... + h2
-                float h1[4], mean, rho;
+                for (int i = 0; i < 4; ++i) d2[i] = dh[i] + dov[i];  // residual branch o = ... + h2
                 ln_fwd_a(hv, h1, mean, rho);
-                float dh1[4], dx[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     dscp[i] += d2[i] * h1[i];
@@ -793,10 +877,6 @@ cnx_bwd_conv_kernel(BwdArgs a) {
                 }
                 ln_bwd_a(dh1, h1, rho, dx);
                 st4((T*)a.dh0 + goff, dx);
-            } else {
-                // keep the cross-lane reductions convergent: every lane of a pixel group
-                // takes the same branch only when the whole 4-lane group is valid/invalid
-                // (gy, gx depend on m only, shared by the 4 q-lanes) -- nothing to do.
             }
         }
     }
@@ -865,7 +945,7 @@ inline int launch_k(K kern, int64_t grid, size_t lds, hipStream_t st, const A& a
 
 template <typename T>
 int fwd_launch(bool jvp, int mode, const FwdArgs& a, int64_t grid, hipStream_t st) {
-    const size_t lds = lds_bytes<T>(jvp);
+    const size_t lds = lds_bytes<T>(jvp, false);
     if (jvp) {
         if (mode == 0) return launch_k(cnx_fwd_kernel<T, true, 0>, grid, lds, st, a);
         return launch_k(cnx_fwd_kernel<T, true, 1>, grid, lds, st, a);
@@ -943,8 +1023,8 @@ extern "C" int mfc_cnx_bwd_stats(int dtype, int64_t R, int s, const void* h0, co
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(nullptr);
     a.g.beta = dbeta; a.q = q; a.dout = dout; a.dq = dq;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFC_F32) return launch_k(cnx_bwd_kernel<float, 0>, grid, lds_bytes<float>(false), st, a);
-    return launch_k(cnx_bwd_kernel<u16, 0>, grid, lds_bytes<u16>(false), st, a);
+    if (dtype == MFC_F32) return launch_k(cnx_bwd_kernel<float, 0>, grid, lds_bytes<float>(false, false), st, a);
+    return launch_k(cnx_bwd_kernel<u16, 0>, grid, lds_bytes<u16>(false, false), st, a);
 }
 
 extern "C" int mfc_cnx_bwd_main(int dtype, int64_t R, int s, const void* h0, const float* scale,
@@ -959,8 +1039,8 @@ extern "C" int mfc_cnx_bwd_main(int dtype, int64_t R, int s, const void* h0, con
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(g);
     a.q = q; a.kG = kG; a.dout = dout; a.dc1 = dc1;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFC_F32) return launch_k(cnx_bwd_kernel<float, 1>, grid, lds_bytes<float>(false), st, a);
-    return launch_k(cnx_bwd_kernel<u16, 1>, grid, lds_bytes<u16>(false), st, a);
+    if (dtype == MFC_F32) return launch_k(cnx_bwd_kernel<float, 1>, grid, lds_bytes<float>(false, true), st, a);
+    return launch_k(cnx_bwd_kernel<u16, 1>, grid, lds_bytes<u16>(false, true), st, a);
 }
 
 extern "C" int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, const float* scale,
@@ -976,6 +1056,6 @@ extern "C" int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, con
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(g);
     a.dc1_in = dc1; a.dout = dout; a.dh0 = dh0; a.dsc = dscale; a.dsh = dshift;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFC_F32) return launch_k(cnx_bwd_conv_kernel<float>, grid, lds_bytes<float>(true), st, a);
-    return launch_k(cnx_bwd_conv_kernel<u16>, grid, lds_bytes<u16>(true), st, a);
+    if (dtype == MFC_F32) return launch_k(cnx_bwd_conv_kernel<float>, grid, lds_bytes<float>(true, false), st, a);
+    return launch_k(cnx_bwd_conv_kernel<u16>, grid, lds_bytes<u16>(true, false), st, a);
 }

@@ -18,12 +18,23 @@ __device__ __host__ inline float bf16_to_f32(u16 h) {
     c.u = ((uint32_t)h) << 16;
     return c.f;
 }
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __host__ inline u16 f32_to_bf16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // gfx950 has v_cvt_pk_bf16_f32 (RNE, NaN kept NaN): one instruction instead of ~7
+    return __builtin_bit_cast(u16, (__bf16)f);
+#else
     union { uint32_t u; float f; } c;
     c.f = f;
     if ((c.u & 0x7fffffffu) > 0x7f800000u) return (u16)((c.u >> 16) | 0x40);  // quiet NaN
     uint32_t r = c.u + 0x7fffu + ((c.u >> 16) & 1u);
     return (u16)(r >> 16);
+#endif
+}
+// two floats -> packed bf16x2 in one v_cvt_pk_bf16_f32
+__device__ inline uint32_t pack_bf16x2(float a, float b) {
+    const bf16x2_t v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 // storage-type traits: T = float or u16 (bf16 bits)
@@ -43,16 +54,26 @@ template <> struct St<u16> {
 // models/mlp_flow.py:29) and its derivative.
 #define MFC_GELU_K0 0.7978845608028654f /* sqrt(2/pi) */
 #define MFC_GELU_K1 0.044715f
-__device__ inline float gelu_f(float x) {
-    float a = MFC_GELU_K0 * (x + MFC_GELU_K1 * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(a));
+// 0.5 (1 + tanh a) = sigmoid(2a): one v_exp_f32 + one v_rcp_f32 instead of tanhf.
+#define MFC_LOG2E 1.4426950408889634f
+__device__ inline float gelu_sig(float x) {
+    // sigmoid(2a) = 1 / (1 + 2^(-2a log2 e)); constants folded, raw v_exp_f32 / v_rcp_f32
+    const float c0 = -2.0f * MFC_GELU_K0 * MFC_LOG2E, c1 = c0 * MFC_GELU_K1;
+    const float t = x * (c0 + c1 * x * x);
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
+__device__ inline float gelu_f(float x) { return x * gelu_sig(x); }
 __device__ inline float gelu_grad_f(float x) {
-    float x2 = x * x;
-    float a = MFC_GELU_K0 * (x + MFC_GELU_K1 * x * x2);
-    float th = tanhf(a);
-    float da = MFC_GELU_K0 * (1.0f + 3.0f * MFC_GELU_K1 * x2);
-    return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * da;
+    const float sg = gelu_sig(x);
+    const float da2 = (2.0f * MFC_GELU_K0) * (1.0f + 3.0f * MFC_GELU_K1 * x * x);
+    return sg + x * sg * (1.0f - sg) * da2;
+}
+// value and derivative sharing the sigmoid
+__device__ inline void gelu_both(float x, float& g, float& dg) {
+    const float sg = gelu_sig(x);
+    const float da2 = (2.0f * MFC_GELU_K0) * (1.0f + 3.0f * MFC_GELU_K1 * x * x);
+    g = x * sg;
+    dg = sg + g * (1.0f - sg) * da2;
 }
 // second derivative, needed for d/dx of (t * gelu'(x)) in the tangent's backward
 // (not on the iMF path: the tangent carries no gradient) -- kept out.
@@ -77,7 +98,9 @@ __device__ inline void mma16(f32x4& acc, const s16x4& a, const s16x4& b) {
 }
 __device__ inline void make_frag(f32x4& f, float a, float b, float c, float d) { f = f32x4{a, b, c, d}; }
 __device__ inline void make_frag(s16x4& f, float a, float b, float c, float d) {
-    f = s16x4{(short)f32_to_bf16(a), (short)f32_to_bf16(b), (short)f32_to_bf16(c), (short)f32_to_bf16(d)};
+    const uint32_t lo = pack_bf16x2(a, b), hi = pack_bf16x2(c, d);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    f = __builtin_bit_cast(s16x4, (u32x2){lo, hi});
 }
 
 static inline int mfc_launch_status() {

@@ -1,0 +1,38 @@
+"""Micro-benchmark of the ConvNeXt-interior kernels at the literal spatial size (s=626).
+usage: python tools/bench_cnx.py [R] [dtype]"""
+import sys, pathlib
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+import torch
+from meanflow_audio_codec_amd import _lib, ops
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+dtype = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "f32") else torch.bfloat16
+s = 626
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(0)
+h0 = torch.randn(R, s, s, 16, device=dev, generator=g).to(dtype)
+h0d = torch.randn(R, s, s, 16, device=dev, generator=g).to(dtype)
+dout = torch.randn(R, s, s, 16, device=dev, generator=g).to(dtype)
+sc = 0.1 * torch.randn(R, 16, device=dev, generator=g); sh = 0.1 * torch.randn(R, 16, device=dev, generator=g)
+w = {"conv_w": (torch.randn(3, 3, 16, 16, device=dev, generator=g) / 12).to(dtype), "conv_b": torch.zeros(16, device=dev),
+     "exp_w": (torch.randn(16, 32, device=dev, generator=g) / 4).to(dtype), "exp_b": torch.zeros(32, device=dev),
+     "grn_gamma": torch.zeros(32, device=dev), "grn_beta": torch.zeros(32, device=dev),
+     "con_w": (torch.randn(32, 16, device=dev, generator=g) / 5.6).to(dtype), "con_b": torch.zeros(16, device=dev),
+     "ls": torch.full((16,), 0.5, device=dev)}
+grads = {k: torch.zeros(v.shape, dtype=torch.float32, device=dev) for k, v in w.items()}
+o, _, G, q = ops.cnx_forward(h0, sc, sh, w, s)
+for rep in range(3):
+    _lib.enable_timing()
+    ops.cnx_forward(h0, sc, sh, w, s)
+    ops.cnx_forward(h0, sc, sh, w, s, h0dot=h0d, scaledot=sc, shiftdot=sh)
+    ops.cnx_backward(h0, sc, sh, w, s, G, q, dout, grads)
+    torch.cuda.synchronize()
+    rec = _lib.disable_timing()
+px = R * s * s
+if True:
+    for name, ints, nn, a, b in rec:
+        if not name.startswith("mfc_cnx"):
+            continue
+        ms = a.elapsed_time(b)
+        jvp = nn[1] if name in ("mfc_cnx_stats", "mfc_cnx_apply") else False
+        print(f"{name:22s} jvp={int(jvp)} {ms:8.3f} ms  {ms * 1e6 / px:7.2f} ns/pixel")
