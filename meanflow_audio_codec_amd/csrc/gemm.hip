@@ -34,6 +34,7 @@ struct GemmArgs {
     int64_t kchunk;  // K range per blockIdx.z
     float* ws;       // split-K workspace (fp32 [M,N]) or null
     int vecA, vecB;  // 4-element vector loads legal
+    int vecC;        // 16-byte row-contiguous C (and R) accesses legal
 };
 
 // load 4 consecutive elements p[0..3] (valid = number in range), zero fill
@@ -171,6 +172,78 @@ gemm_kernel(GemmArgs g) {
     // epilogue.  C layout of a 16x16 MFMA tile: col = lane&15, row = 4*(lane>>4)+reg
     T* C = (T*)g.C;
     const T* R = (const T*)g.R;
+    if (!g.ws && g.vecC) {
+        // Row-contiguous stores: each wave transposes its 64x64 result 16 rows at a time through a
+        // private LDS slab so every lane writes 16 consecutive columns (32/64 B) of one row --
+        // 16x fewer (and full-line) store instructions than storing the MFMA C layout directly.
+        constexpr int CSS = 68;
+        float* cs = reinterpret_cast<float*>(lds) + wave * (16 * CSS);
+        const int lr = lane >> 2, lc = (lane & 3) * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cs[(4 * q + e) * CSS + 16 * j + r] = acc[i][j][e];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int64_t row = m0 + wm + 16 * i + lr;
+            const int64_t col0 = n0 + wn + lc;
+            float v[16];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(cs + lr * CSS + lc + 4 * k4);
+                v[4 * k4] = t[0]; v[4 * k4 + 1] = t[1]; v[4 * k4 + 2] = t[2]; v[4 * k4 + 3] = t[3];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (row < g.M && col0 < g.N) {
+                const bool hb = g.bias && row < g.bias_rows;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] = (v[k] + (hb ? g.bias[col0 + k] : 0.f)) * g.alpha;
+                T* cp = C + row * g.ldc + col0;
+                if constexpr (sizeof(T) == 4) {
+                    if (R) {
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; ++k4) {
+                            const f32x4 t = *reinterpret_cast<const f32x4*>(R + row * g.ldr + col0 + 4 * k4);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[4 * k4 + k] += g.beta * t[k];
+                        }
+                    }
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        f32x4 t = f32x4{v[4 * k4], v[4 * k4 + 1], v[4 * k4 + 2], v[4 * k4 + 3]};
+                        if (g.accum) t += *reinterpret_cast<const f32x4*>(cp + 4 * k4);
+                        *reinterpret_cast<f32x4*>(cp + 4 * k4) = t;
+                    }
+                } else {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    if (R) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const s16x8 t = *reinterpret_cast<const s16x8*>(R + row * g.ldr + col0 + 8 * h);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[8 * h + k] += g.beta * bf16_to_f32((u16)t[k]);
+                        }
+                    }
+                    if (g.accum) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const s16x8 t = *reinterpret_cast<const s16x8*>(cp + 8 * h);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[8 * h + k] += bf16_to_f32((u16)t[k]);
+                        }
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const u32x4 t = {pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                                         pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+                        *reinterpret_cast<u32x4*>(cp + 8 * h) = t;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -282,6 +355,8 @@ extern "C" int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
     // 4-element vector loads need the run start 4-element aligned for every row
     g.vecA = ((lda % 4) == 0) && (((uintptr_t)A % (4 * es)) == 0);
     g.vecB = ((ldb % 4) == 0) && (((uintptr_t)B % (4 * es)) == 0);
+    g.vecC = (N % 16 == 0) && ((ldc * es) % 16 == 0) && (((uintptr_t)C % 16) == 0) &&
+             (!R || (((ldr * es) % 16 == 0) && (((uintptr_t)R % 16) == 0)));
     if (use_ws) {
         if (hipMemsetAsync(ws, 0, (size_t)M * N * sizeof(float), st) != hipSuccess) return MFC_EHIP;
     }
