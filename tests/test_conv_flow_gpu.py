@@ -142,3 +142,26 @@ def test_train_step_updates_like_oracle():
         # step 1 of Adam moves every weight by ~lr*sign(g): compare where |g| is not tiny
         mask = gr[k].abs() > 1e-3 * gr[k].abs().max()
         assert ((state.params[k].double().cpu() - pn)[mask].abs().max() < 2e-5), k
+
+
+def test_data_parallel_shards_sum_to_global_batch():
+    """Two shards (row0 / global_batch) give gradients and losses that SUM to the full-batch step:
+    what the RCCL all-reduce of distributed.GradReducer relies on."""
+    from meanflow_audio_codec_amd.trainers import ImprovedMeanFlowLoss, PRNGKey
+    model, state, pq = _make(torch.float32, seed=11)
+    x, e, t, r = _draws(8, seed=12)
+    strat = ImprovedMeanFlowLoss()
+    loss_full, grads = strat.compute_loss(state, PRNGKey(0), x.cuda(), e=e.cuda(), t=t.cuda(), r=r.cuda())
+    full = {k: v.double().clone() for k, v in grads.items()}
+    acc = {k: torch.zeros_like(v) for k, v in full.items()}
+    loss_sum = 0.0
+    for sl in (slice(0, 4), slice(4, 8)):
+        l, g = strat.compute_loss(state, PRNGKey(0), x[sl].cuda(), e=e[sl].cuda(), t=t[sl].cuda(), r=r[sl].cuda(),
+                                  row0=sl.start, global_batch=8)
+        loss_sum += l.item()
+        for k in acc:
+            acc[k] += g[k].double()
+    assert abs(loss_sum - loss_full.item()) < 1e-5
+    for k in full:
+        if full[k].abs().max() > 0:
+            assert ((acc[k] - full[k]).abs().max() / full[k].abs().max()).item() < 2e-3, k
