@@ -9,7 +9,7 @@
 //   input gradient     dX[R,K] = dY[R,N] W[K,N]^T         (NT)
 //   weight gradient    dW[K,N] = X[R,K]^T dY[R,N]         (TN)
 //
-// 128x128x32 workgroup tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles of
+// 128x128xBK workgroup tile (BK = 64; 32 for tiny K), 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles of
 // 16x16.  fp32 storage -> v_mfma_f32_16x16x4_f32 (exact fp32 fma chain);
 // bf16 storage -> v_mfma_f32_16x16x16_bf16.  Both read 4 contiguous k per
 // lane from K-contiguous LDS tiles, so one staging/addressing scheme serves
@@ -18,9 +18,12 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, GT = 256;
-constexpr int LDS_PAD = 4;
-constexpr int LDK = BK + LDS_PAD;  // elements per LDS row
+constexpr int BM = 128, BN = 128, GT = 256;
+constexpr int ldk_of(int BK, int es) { return BK + 16 / es; }   // K-contiguous tile [128][LDK]: +16 B pad
+constexpr int ldr_of(int es) { return es == 4 ? 132 : 144; }     // row-contiguous tile [BK][LDR]
+constexpr int tile_elems(int BK, int es) {
+    return 128 * ldk_of(BK, es) > BK * ldr_of(es) ? 128 * ldk_of(BK, es) : BK * ldr_of(es);
+}
 
 struct GemmArgs {
     int64_t M, N, K;
@@ -33,94 +36,120 @@ struct GemmArgs {
     int accum;
     int64_t kchunk;  // K range per blockIdx.z
     float* ws;       // split-K workspace (fp32 [M,N]) or null
-    int vecA, vecB;  // 4-element vector loads legal
+    int vecA, vecB;  // 16-byte vector loads legal
     int vecC;        // 16-byte row-contiguous C (and R) accesses legal
 };
 
-// load 4 consecutive elements p[0..3] (valid = number in range), zero fill
+template <typename T> struct Vec;   // 16-byte global vector
+template <> struct Vec<float> { typedef f32x4 type; static constexpr int W = 4; };
+template <> struct Vec<u16> { typedef s16x8 type; static constexpr int W = 8; };
+
+// load W consecutive elements (valid = number in range), zero fill
 template <typename T>
-__device__ inline void load4(const T* p, int64_t valid, bool vec, T out[4]) {
-    if (vec && valid >= 4) {
-        if constexpr (sizeof(T) == 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-            out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
-        } else {
-            const s16x4 v = *reinterpret_cast<const s16x4*>(p);
-            out[0] = (T)v[0]; out[1] = (T)v[1]; out[2] = (T)v[2]; out[3] = (T)v[3];
-        }
+__device__ inline void loadv(const T* p, int64_t valid, bool vec, T* out) {
+    constexpr int W = Vec<T>::W;
+    if (vec && valid >= W) {
+        const typename Vec<T>::type v = *reinterpret_cast<const typename Vec<T>::type*>(p);
+#pragma unroll
+        for (int i = 0; i < W; ++i) out[i] = (T)v[i];
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) out[i] = (i < valid) ? p[i] : (T)0;
+        for (int i = 0; i < W; ++i) out[i] = (i < valid) ? p[i] : (T)0;
     }
 }
 
-// Stage one operand tile (ROWS x BK, ROWS = 128) into registers.
+// Stage one operand tile (128 rows x BK) into registers / from registers into LDS.
 //  KC = true : source is K-contiguous   src[row*ld + k]
 //  KC = false: source is row-contiguous src[k*ld + row]
-template <typename T, bool KC>
-__device__ inline void tile_load(const T* src, int64_t ld, int64_t row0, int64_t nrows,
-                                 int64_t k0, int64_t kend, bool vec, T regs[16]) {
-    const int t = threadIdx.x;
-    if constexpr (KC) {
-        // 8 threads per row (4 k each), 32 rows per pass, 4 passes
-        const int kk = (t & 7) * 4;
-        const int rr = t >> 3;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int64_t row = row0 + rr + 32 * p;
-            const int64_t k = k0 + kk;
-            if (row < nrows && k < kend) load4<T>(src + row * ld + k, kend - k, vec, &regs[4 * p]);
-            else { regs[4 * p] = regs[4 * p + 1] = regs[4 * p + 2] = regs[4 * p + 3] = (T)0; }
-        }
-    } else {
-        // wave w covers k rows [8w, 8w+8); lane: lk = lane&7, lm = lane>>3 -> 4 rows each
-        const int lane = t & 63, w = t >> 6;
-        const int lk = lane & 7, lm = lane >> 3;
-        const int64_t k = k0 + 8 * w + lk;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int64_t row = row0 + 32 * p + 4 * lm;
-            if (k < kend && row < nrows) load4<T>(src + k * ld + row, nrows - row, vec, &regs[4 * p]);
-            else { regs[4 * p] = regs[4 * p + 1] = regs[4 * p + 2] = regs[4 * p + 3] = (T)0; }
-        }
-    }
-}
+template <typename T, int BK, bool KC> struct Stage {
+    static constexpr int W = Vec<T>::W;
+    static constexpr int LDK = ldk_of(BK, sizeof(T));
+    // KC geometry
+    static constexpr int TPR = BK / W, RPP = GT / TPR, NP = 128 / RPP;
+    // !KC geometry: the tile stays [k][row] in LDS (no transpose on the way in): 128/W threads per
+    // k-row, 2W k-rows per pass
+    static constexpr int LDR = ldr_of(sizeof(T));
+    static constexpr int TPK = 128 / W, KPP = GT / TPK, NPT = BK / KPP;
+    static constexpr int NREG = KC ? NP * W : NPT * W;
 
-template <typename T, bool KC>
-__device__ inline void tile_store(T* lds, const T regs[16]) {
-    const int t = threadIdx.x;
-    if constexpr (KC) {
-        const int kk = (t & 7) * 4;
-        const int rr = t >> 3;
+    __device__ static inline void load(const T* src, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
+                                       int64_t kend, bool vec, T* regs) {
+        const int t = threadIdx.x;
+        if constexpr (KC) {
+            const int kk = (t % TPR) * W, rr = t / TPR;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            T* d = lds + (rr + 32 * p) * LDK + kk;
-            if constexpr (sizeof(T) == 4) {
-                *reinterpret_cast<f32x4*>(d) = f32x4{regs[4 * p], regs[4 * p + 1], regs[4 * p + 2], regs[4 * p + 3]};
-            } else {
-                *reinterpret_cast<s16x4*>(d) = s16x4{(short)regs[4 * p], (short)regs[4 * p + 1],
-                                                     (short)regs[4 * p + 2], (short)regs[4 * p + 3]};
+            for (int p = 0; p < NP; ++p) {
+                const int64_t row = row0 + rr + RPP * p, k = k0 + kk;
+                if (row < nrows && k < kend) loadv<T>(src + row * ld + k, kend - k, vec, regs + W * p);
+                else {
+#pragma unroll
+                    for (int i = 0; i < W; ++i) regs[W * p + i] = (T)0;
+                }
+            }
+        } else {
+            const int rr = (t % TPK) * W, kk = t / TPK;
+#pragma unroll
+            for (int p = 0; p < NPT; ++p) {
+                const int64_t k = k0 + kk + KPP * p, row = row0 + rr;
+                if (k < kend && row < nrows) loadv<T>(src + k * ld + row, nrows - row, vec, regs + W * p);
+                else {
+#pragma unroll
+                    for (int i = 0; i < W; ++i) regs[W * p + i] = (T)0;
+                }
             }
         }
-    } else {
-        const int lane = t & 63, w = t >> 6;
-        const int lk = lane & 7, lm = lane >> 3;
-        const int k = 8 * w + lk;
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) lds[(32 * p + 4 * lm + i) * LDK + k] = regs[4 * p + i];
     }
-}
+    __device__ static inline void store(T* lds, const T* regs) {
+        const int t = threadIdx.x;
+        if constexpr (KC) {
+            const int kk = (t % TPR) * W, rr = t / TPR;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                typename Vec<T>::type v;
+#pragma unroll
+                for (int i = 0; i < W; ++i) v[i] = regs[W * p + i];
+                *reinterpret_cast<typename Vec<T>::type*>(lds + (rr + RPP * p) * LDK + kk) = v;
+            }
+        } else {
+            const int rr = (t % TPK) * W, kk = t / TPK;
+#pragma unroll
+            for (int p = 0; p < NPT; ++p) {
+                typename Vec<T>::type v;
+#pragma unroll
+                for (int i = 0; i < W; ++i) v[i] = regs[W * p + i];
+                *reinterpret_cast<typename Vec<T>::type*>(lds + (kk + KPP * p) * LDR + rr) = v;
+            }
+        }
+    }
 
-template <typename T, bool TA, bool TB>
+    // MFMA operand fragment of tile row (rowbase + r), k = 16c + 4q .. +3
+    __device__ static inline typename Frag<T>::type fetch(const T* S, int rowbase, int c, int q, int r) {
+        typedef typename Frag<T>::type frag_t;
+        if constexpr (KC) {
+            return *reinterpret_cast<const frag_t*>(S + (rowbase + r) * LDK + 16 * c + 4 * q);
+        } else if constexpr (sizeof(T) == 4) {
+            const T* p = S + (16 * c + 4 * q) * LDR + rowbase + r;
+            return frag_t{p[0], p[LDR], p[2 * LDR], p[3 * LDR]};
+        } else {
+            // gfx950 LDS transpose read: the 16 lanes of group q fetch the 4(k) x 16(row) block and each
+            // receives one row's 4 consecutive k -- lane 4q'+p supplies the address of k-row q', rows 4p..4p+3
+            const T* p = S + (16 * c + 4 * q + (r >> 2)) * LDR + rowbase + 4 * (r & 3);
+            return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+        }
+    }
+};
+
+template <typename T, int BK, bool TA, bool TB>
 __global__ void __launch_bounds__(GT)
 gemm_kernel(GemmArgs g) {
-    // A tile: [BM][LDK], B tile: [BN][LDK], both K-contiguous in LDS
-    __shared__ __attribute__((aligned(16))) T lds[(BM + BN) * LDK];
+    // operand tiles: [128][LDK] when the source is K-contiguous, [BK][LDR] when it is row-contiguous
+    constexpr int TE = tile_elems(BK, sizeof(T));
+    __shared__ __attribute__((aligned(16))) T lds[2 * TE];
     T* As = lds;
-    T* Bs = lds + BM * LDK;
+    T* Bs = lds + TE;
     typedef typename Frag<T>::type frag_t;
+    typedef Stage<T, BK, !TA> SA;   // A: K-contiguous when not transposed ([M][K])
+    typedef Stage<T, BK, TB> SB;    // B: K-contiguous when transposed ([N][K])
 
     const T* A = (const T*)g.A;
     const T* B = (const T*)g.B;
@@ -139,28 +168,27 @@ gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    T ra[16], rb[16];
-    // A: K-contiguous when not transposed ([M][K]); B: K-contiguous when transposed ([N][K])
-    tile_load<T, !TA>(A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
-    tile_load<T, TB>(B, g.ldb, n0, g.N, kbeg, kend, g.vecB, rb);
+    T ra[SA::NREG], rb[SB::NREG];
+    SA::load(A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
+    SB::load(B, g.ldb, n0, g.N, kbeg, kend, g.vecB, rb);
 
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-        tile_store<T, !TA>(As, ra);
-        tile_store<T, TB>(Bs, rb);
+        SA::store(As, ra);
+        SB::store(Bs, rb);
         __syncthreads();
-        if (k0 + BK < kend) {
-            tile_load<T, !TA>(A, g.lda, m0, g.M, k0 + BK, kend, g.vecA, ra);
-            tile_load<T, TB>(B, g.ldb, n0, g.N, k0 + BK, kend, g.vecB, rb);
+        if (k0 + BK < kend) {   // next tile's global loads fly during the MFMAs
+            SA::load(A, g.lda, m0, g.M, k0 + BK, kend, g.vecA, ra);
+            SB::load(B, g.ldb, n0, g.N, k0 + BK, kend, g.vecB, rb);
         }
 #pragma unroll
         for (int c = 0; c < BK / 16; ++c) {
             frag_t af[4], bf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                af[i] = *reinterpret_cast<const frag_t*>(As + (wm + 16 * i + r) * LDK + 16 * c + 4 * q);
+                af[i] = SA::fetch(As, wm + 16 * i, c, q, r);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                bf[j] = *reinterpret_cast<const frag_t*>(Bs + (wn + 16 * j + r) * LDK + 16 * c + 4 * q);
+                bf[j] = SB::fetch(Bs, wn + 16 * j, c, q, r);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -298,14 +326,20 @@ gemm_epilogue_kernel(const float* ws, int64_t M, int64_t N, T* C, int64_t ldc,
     }
 }
 
+template <typename T, int BK>
+void launch_bk(bool ta, bool tb, dim3 grid, const GemmArgs& g, hipStream_t st) {
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, BK, false, false>), grid, dim3(GT), 0, st, g);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, BK, false, true>), grid, dim3(GT), 0, st, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, BK, true, false>), grid, dim3(GT), 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<T, BK, true, true>), grid, dim3(GT), 0, st, g);
+}
+
 template <typename T>
-int launch(int flags, const GemmArgs& g, int splitk, int gelu, int64_t act_rows, hipStream_t st) {
+int launch(int flags, const GemmArgs& g, int bk, int splitk, int gelu, int64_t act_rows, hipStream_t st) {
     dim3 grid((unsigned)ceil_div64(g.N, BN), (unsigned)ceil_div64(g.M, BM), (unsigned)splitk);
     const bool ta = flags & MFC_GEMM_TRANS_A, tb = flags & MFC_GEMM_TRANS_B;
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, dim3(GT), 0, st, g);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, dim3(GT), 0, st, g);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, dim3(GT), 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, dim3(GT), 0, st, g);
+    if (bk == 32) launch_bk<T, 32>(ta, tb, grid, g, st);
+    else launch_bk<T, 64>(ta, tb, grid, g, st);
     int rc = mfc_launch_status();
     if (rc) return rc;
     if (g.ws) {
@@ -347,19 +381,20 @@ extern "C" int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
     g.bias = bias; g.bias_rows = bias_rows;
     g.alpha = alpha; g.R = R; g.ldr = ldr; g.beta = beta_res;
     g.accum = (flags & MFC_GEMM_ACCUM) ? 1 : 0;
-    int64_t kc = ceil_div64(ceil_div64(K, splitk), BK) * BK;
+    const int bk = K <= 32 ? 32 : 64;    // K-step of the LDS tiles
+    int64_t kc = ceil_div64(ceil_div64(K, splitk), bk) * bk;
     g.kchunk = kc;
     splitk = (int)ceil_div64(K, kc);
     const bool use_ws = (splitk > 1) || gelu;
     g.ws = use_ws ? ws : nullptr;
-    // 4-element vector loads need the run start 4-element aligned for every row
-    g.vecA = ((lda % 4) == 0) && (((uintptr_t)A % (4 * es)) == 0);
-    g.vecB = ((ldb % 4) == 0) && (((uintptr_t)B % (4 * es)) == 0);
+    // 16-byte vector loads need every row start 16-byte aligned
+    g.vecA = (((lda * es) % 16) == 0) && (((uintptr_t)A % 16) == 0);
+    g.vecB = (((ldb * es) % 16) == 0) && (((uintptr_t)B % 16) == 0);
     g.vecC = (N % 16 == 0) && ((ldc * es) % 16 == 0) && (((uintptr_t)C % 16) == 0) &&
              (!R || (((ldr * es) % 16 == 0) && (((uintptr_t)R % 16) == 0)));
     if (use_ws) {
         if (hipMemsetAsync(ws, 0, (size_t)M * N * sizeof(float), st) != hipSuccess) return MFC_EHIP;
     }
-    return dtype == MFC_F32 ? launch<float>(flags, g, splitk, gelu, act_rows, st)
-                            : launch<u16>(flags, g, splitk, gelu, act_rows, st);
+    return dtype == MFC_F32 ? launch<float>(flags, g, bk, splitk, gelu, act_rows, st)
+                            : launch<u16>(flags, g, bk, splitk, gelu, act_rows, st);
 }
