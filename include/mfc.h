@@ -237,6 +237,35 @@ int mfc_adamw(int grad_dtype, int64_t n, float* p, void* p_bf16, const void* g, 
               float* m, float* v, float lr, float b1, float b2, float eps, float wd, int64_t step,
               void* stream);
 
+/* ------------------------------------------------------------------ */
+/* AdaLN / gating (MLP and MLP-Mixer velocity nets)                    */
+/* ------------------------------------------------------------------ */
+/* y = (1 + scale) * LN(x) + shift over the last axis (flax LayerNorm, no affine, eps 1e-6):
+ * models/mlp_flow.py:96-110 (ConditionalResidualBlock), models/mlp_mixer.py AdaLN.
+ * x,y [rows, W] dtype with leading dims ldx/ldy; modulation element of (row, col) is
+ * mod[(row / mod_div) * ldm + col].  Rows >= act_rows are forward-mode tangents of rows
+ * [0, rows-act_rows): their x/scale/shift rows hold xdot/scaledot/shiftdot. */
+int mfc_adaln_fwd(int dtype, int64_t rows, int64_t act_rows, int64_t W, const void* x, int64_t ldx,
+                  const void* scale, const void* shift, int64_t ldm, int64_t mod_div, void* y,
+                  int64_t ldy, void* stream);
+/* reverse pass: dx, dscale = dy*LN(x), dshift = dy.  mod_div == 1: dscale/dshift dtype [rows, W]
+ * (ldd); mod_div > 1: fp32 [rows/mod_div, W] accumulated with atomics (zeroed by the caller). */
+int mfc_adaln_bwd(int dtype, int64_t rows, int64_t W, const void* x, int64_t ldx, const void* scale,
+                  int64_t ldm, int64_t mod_div, const void* dy, int64_t ldy, void* dx, void* dscale,
+                  void* dshift, int64_t ldd, void* stream);
+/* out = o * (1 + s2) * inv_k + res (models/mlp_flow.py:116-117) with tangent rows, and its reverse
+ * (do = dy (1+s2) inv_k, ds2 = dy o inv_k; dres = dy). */
+int mfc_gate_fwd(int dtype, int64_t rows, int64_t act_rows, int64_t W, const void* o, int64_t ldo,
+                 const void* s2, int64_t ldm, const void* res, int64_t ldr, float inv_k, void* y,
+                 int64_t ldy, void* stream);
+int mfc_gate_bwd(int dtype, int64_t rows, int64_t W, const void* dy, int64_t ldy, const void* o,
+                 int64_t ldo, const void* s2, int64_t ldm, float inv_k, void* dout_o, void* ds2,
+                 int64_t ldd, void* stream);
+/* dst[r,c] = (accumulate ? dst : 0) + alpha * src[r,c] on strided 2-D views (concat / slice plumbing
+ * of models/mlp_flow.py:190-194 without intermediate tensors). */
+int mfc_copy2d(int dtype, int64_t rows, int64_t W, const void* src, int64_t lds, void* dst, int64_t ldd,
+               float alpha, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,14 @@ SIGNATURES = {
     "mfc_grn_bwd_finalize": (c_int, [c_int64, _P, _P, _P, _P, _P]),
     "mfc_cnx_bwd_main": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_cnx_bwd_conv": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_adaln_fwd": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, _P]),
+    "mfc_adaln_bwd": (c_int, [c_int, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int64, _P, c_int64, _P, _P, _P,
+                              c_int64, _P]),
+    "mfc_gate_fwd": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_float, _P,
+                             c_int64, _P]),
+    "mfc_gate_bwd": (c_int, [c_int, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_float, _P, _P, c_int64,
+                             _P]),
+    "mfc_copy2d": (c_int, [c_int, c_int64, c_int64, _P, c_int64, _P, c_int64, c_float, c_int, _P]),
     "mfc_time_embed": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_sample_tr": (c_int, [c_uint64, c_uint64, c_int64, c_int64, c_int64, c_float, c_float, c_float, c_int,
                               _P, _P, _P]),

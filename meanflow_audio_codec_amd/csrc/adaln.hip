@@ -1,0 +1,250 @@
+// AdaLN / gating kernels of the MLP and MLP-Mixer velocity nets (HBM-bound row kernels).
+//
+//   adaln   : y = (1 + scale) * LN(x) + shift        models/mlp_flow.py:96-110, models/mlp_mixer.py (AdaLN)
+//   gate    : out = o * (1 + s2) * inv_k + res        models/mlp_flow.py:116-117
+// each with its forward-mode tangent (row-stacked: rows >= act_rows are the tangents of rows
+// [0, n_tan)) and its reverse pass.  LN = flax LayerNorm without affine, eps 1e-6, last axis.
+// Modulation tensors are addressed as mod[(row / mod_div) * ldm + col], so per-row modulation
+// (MLP flow: mod_div = 1, views into the conditioning MLP's output) and per-sample modulation
+// broadcast over tokens (Mixer: mod_div = tokens per sample) share the kernels.
+#include "mfc_common.h"
+
+namespace {
+
+constexpr int AT = 256;
+
+__device__ inline float block_sum(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < AT / 64; ++i) s += red[i];
+    return s;
+}
+
+struct AdaArgs {
+    int64_t rows, act_rows, W, ldx, ldm, ldy, mod_div;
+    const void* x; const void* scale; const void* shift; void* y;
+    const void* dy; void* dx; void* dscale; void* dshift; int64_t ldd;
+    float inv_k;
+};
+
+// one workgroup per row (primal rows and tangent rows)
+template <typename T>
+__global__ void __launch_bounds__(AT) adaln_fwd_kernel(AdaArgs a) {
+    __shared__ float red[AT / 64];
+    const int64_t row = blockIdx.x;
+    const bool tan = row >= a.act_rows;
+    const int64_t prow = tan ? row - a.act_rows : row;     // the primal row this row belongs to
+    const T* xp = (const T*)a.x + prow * a.ldx;
+    const T* sc = (const T*)a.scale + (prow / a.mod_div) * a.ldm;
+    const T* sh = (const T*)a.shift + (prow / a.mod_div) * a.ldm;
+    const int64_t W = a.W;
+    float s = 0.f, ss = 0.f;
+    for (int64_t c = threadIdx.x; c < W; c += AT) { const float v = St<T>::ld(xp + c); s += v; ss += v * v; }
+    const float mean = block_sum(s, red) / (float)W;
+    const float var = fmaxf(0.f, block_sum(ss, red) / (float)W - mean * mean);
+    const float rho = rsqrtf(var + 1e-6f);
+    T* yp = (T*)a.y + row * a.ldy;
+    if (!tan) {
+        for (int64_t c = threadIdx.x; c < W; c += AT) {
+            const float n = (St<T>::ld(xp + c) - mean) * rho;
+            St<T>::st(yp + c, (1.0f + St<T>::ld(sc + c)) * n + St<T>::ld(sh + c));
+        }
+        return;
+    }
+    // tangent row: ydot = scdot * n + (1 + sc) * ndot + shdot, ndot = rho (xd_c - n mean(n xd_c))
+    const T* xd = (const T*)a.x + row * a.ldx;
+    const T* scd = (const T*)a.scale + (row / a.mod_div) * a.ldm;
+    const T* shd = (const T*)a.shift + (row / a.mod_div) * a.ldm;
+    float sd = 0.f;
+    for (int64_t c = threadIdx.x; c < W; c += AT) sd += St<T>::ld(xd + c);
+    const float md = block_sum(sd, red) / (float)W;
+    float dt = 0.f;
+    for (int64_t c = threadIdx.x; c < W; c += AT)
+        dt += (St<T>::ld(xp + c) - mean) * rho * (St<T>::ld(xd + c) - md);
+    const float dot = block_sum(dt, red) / (float)W;
+    for (int64_t c = threadIdx.x; c < W; c += AT) {
+        const float n = (St<T>::ld(xp + c) - mean) * rho;
+        const float nd = rho * (St<T>::ld(xd + c) - md - n * dot);
+        St<T>::st(yp + c, St<T>::ld(scd + c) * n + (1.0f + St<T>::ld(sc + c)) * nd + St<T>::ld(shd + c));
+    }
+}
+
+// reverse: dscale = dy * n ; dshift = dy ; dx = LN-bwd(dy * (1 + scale))
+// mod_div > 1 (modulation shared by mod_div rows): dscale/dshift are reduced with fp32 atomics into
+// [rows/mod_div, W] fp32 buffers (zeroed by the caller); mod_div == 1: written in T.
+template <typename T>
+__global__ void __launch_bounds__(AT) adaln_bwd_kernel(AdaArgs a) {
+    __shared__ float red[AT / 64];
+    const int64_t row = blockIdx.x;
+    const T* xp = (const T*)a.x + row * a.ldx;
+    const T* sc = (const T*)a.scale + (row / a.mod_div) * a.ldm;
+    const T* dyp = (const T*)a.dy + row * a.ldy;
+    const int64_t W = a.W;
+    float s = 0.f, ss = 0.f;
+    for (int64_t c = threadIdx.x; c < W; c += AT) { const float v = St<T>::ld(xp + c); s += v; ss += v * v; }
+    const float mean = block_sum(s, red) / (float)W;
+    const float var = fmaxf(0.f, block_sum(ss, red) / (float)W - mean * mean);
+    const float rho = rsqrtf(var + 1e-6f);
+    float m1 = 0.f, m2 = 0.f;
+    for (int64_t c = threadIdx.x; c < W; c += AT) {
+        const float n = (St<T>::ld(xp + c) - mean) * rho;
+        const float dn = St<T>::ld(dyp + c) * (1.0f + St<T>::ld(sc + c));
+        m1 += dn; m2 += dn * n;
+    }
+    m1 = block_sum(m1, red) / (float)W;
+    m2 = block_sum(m2, red) / (float)W;
+    T* dxp = (T*)a.dx + row * a.ldx;
+    for (int64_t c = threadIdx.x; c < W; c += AT) {
+        const float n = (St<T>::ld(xp + c) - mean) * rho;
+        const float dyv = St<T>::ld(dyp + c);
+        const float dn = dyv * (1.0f + St<T>::ld(sc + c));
+        St<T>::st(dxp + c, rho * (dn - m1 - n * m2));
+        if (a.mod_div == 1) {
+            St<T>::st((T*)a.dscale + row * a.ldd + c, dyv * n);
+            St<T>::st((T*)a.dshift + row * a.ldd + c, dyv);
+        } else {
+            atomicAdd((float*)a.dscale + (row / a.mod_div) * a.ldd + c, dyv * n);
+            atomicAdd((float*)a.dshift + (row / a.mod_div) * a.ldd + c, dyv);
+        }
+    }
+}
+
+struct GateArgs {
+    int64_t rows, act_rows, W, ldo, ldm, ldr, ldy;
+    const void* o; const void* s2; const void* res; void* y;
+    const void* dy; void* dox; void* ds2; int64_t ldd;
+    float inv_k;
+};
+
+// out = o (1 + s2) inv_k + res ; tangent rows: (odot (1 + s2) + o s2dot) inv_k + resdot
+template <typename T>
+__global__ void __launch_bounds__(AT) gate_fwd_kernel(GateArgs a) {
+    const int64_t total = a.rows * a.W;
+    for (int64_t i = blockIdx.x * (int64_t)AT + threadIdx.x; i < total; i += (int64_t)gridDim.x * AT) {
+        const int64_t row = i / a.W, c = i - row * a.W;
+        const float o = St<T>::ld((const T*)a.o + row * a.ldo + c);
+        const float s2 = St<T>::ld((const T*)a.s2 + row * a.ldm + c);
+        const float r = St<T>::ld((const T*)a.res + row * a.ldr + c);
+        float v;
+        if (row < a.act_rows) v = o * (1.0f + s2) * a.inv_k + r;
+        else {
+            const int64_t pr = row - a.act_rows;
+            const float op = St<T>::ld((const T*)a.o + pr * a.ldo + c);
+            const float sp = St<T>::ld((const T*)a.s2 + pr * a.ldm + c);
+            v = (o * (1.0f + sp) + op * s2) * a.inv_k + r;
+        }
+        St<T>::st((T*)a.y + row * a.ldy + c, v);
+    }
+}
+
+// do = dy (1 + s2) inv_k ; ds2 = dy o inv_k   (dres = dy, taken by the caller)
+template <typename T>
+__global__ void __launch_bounds__(AT) gate_bwd_kernel(GateArgs a) {
+    const int64_t total = a.rows * a.W;
+    for (int64_t i = blockIdx.x * (int64_t)AT + threadIdx.x; i < total; i += (int64_t)gridDim.x * AT) {
+        const int64_t row = i / a.W, c = i - row * a.W;
+        const float dy = St<T>::ld((const T*)a.dy + row * a.ldy + c);
+        const float o = St<T>::ld((const T*)a.o + row * a.ldo + c);
+        const float s2 = St<T>::ld((const T*)a.s2 + row * a.ldm + c);
+        St<T>::st((T*)a.dox + row * a.ldo + c, dy * (1.0f + s2) * a.inv_k);
+        St<T>::st((T*)a.ds2 + row * a.ldd + c, dy * o * a.inv_k);
+    }
+}
+
+// strided 2-D copy / accumulate: dst[r, c] (+)= alpha * src[r, c]
+template <typename T>
+__global__ void __launch_bounds__(AT) copy2d_kernel(int64_t rows, int64_t W, const T* src, int64_t lds_, T* dst,
+                                                    int64_t ldd, float alpha, int accum) {
+    const int64_t total = rows * W;
+    for (int64_t i = blockIdx.x * (int64_t)AT + threadIdx.x; i < total; i += (int64_t)gridDim.x * AT) {
+        const int64_t row = i / W, c = i - row * W;
+        float v = alpha * St<T>::ld(src + row * lds_ + c);
+        if (accum) v += St<T>::ld(dst + row * ldd + c);
+        St<T>::st(dst + row * ldd + c, v);
+    }
+}
+
+inline unsigned grid1d(int64_t n) {
+    int64_t b = ceil_div64(n, AT);
+    return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+#define DT_OK(dt) ((dt) == MFC_F32 || (dt) == MFC_BF16)
+
+extern "C" int mfc_adaln_fwd(int dtype, int64_t rows, int64_t act_rows, int64_t W, const void* x, int64_t ldx,
+                             const void* scale, const void* shift, int64_t ldm, int64_t mod_div, void* y,
+                             int64_t ldy, void* stream) {
+    if (!x || !scale || !shift || !y) return MFC_EFAULT;
+    if (rows <= 0 || W <= 0 || act_rows <= 0 || act_rows > rows || rows > 2 * act_rows || ldx < W || ldy < W ||
+        mod_div < 1 || !DT_OK(dtype))
+        return MFC_EINVAL;
+    AdaArgs a = {};
+    a.rows = rows; a.act_rows = act_rows; a.W = W; a.ldx = ldx; a.ldm = ldm; a.ldy = ldy; a.mod_div = mod_div;
+    a.x = x; a.scale = scale; a.shift = shift; a.y = y;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_F32) hipLaunchKernelGGL(adaln_fwd_kernel<float>, dim3((unsigned)rows), dim3(AT), 0, st, a);
+    else hipLaunchKernelGGL(adaln_fwd_kernel<u16>, dim3((unsigned)rows), dim3(AT), 0, st, a);
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_adaln_bwd(int dtype, int64_t rows, int64_t W, const void* x, int64_t ldx, const void* scale,
+                             int64_t ldm, int64_t mod_div, const void* dy, int64_t ldy, void* dx, void* dscale,
+                             void* dshift, int64_t ldd, void* stream) {
+    if (!x || !scale || !dy || !dx || !dscale || !dshift) return MFC_EFAULT;
+    if (rows <= 0 || W <= 0 || ldx < W || ldy < W || ldd < W || mod_div < 1 || !DT_OK(dtype)) return MFC_EINVAL;
+    AdaArgs a = {};
+    a.rows = rows; a.W = W; a.ldx = ldx; a.ldm = ldm; a.ldy = ldy; a.mod_div = mod_div; a.ldd = ldd;
+    a.x = x; a.scale = scale; a.dy = dy; a.dx = dx; a.dscale = dscale; a.dshift = dshift;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_F32) hipLaunchKernelGGL(adaln_bwd_kernel<float>, dim3((unsigned)rows), dim3(AT), 0, st, a);
+    else hipLaunchKernelGGL(adaln_bwd_kernel<u16>, dim3((unsigned)rows), dim3(AT), 0, st, a);
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_gate_fwd(int dtype, int64_t rows, int64_t act_rows, int64_t W, const void* o, int64_t ldo,
+                            const void* s2, int64_t ldm, const void* res, int64_t ldr, float inv_k, void* y,
+                            int64_t ldy, void* stream) {
+    if (!o || !s2 || !res || !y) return MFC_EFAULT;
+    if (rows <= 0 || W <= 0 || act_rows <= 0 || act_rows > rows || rows > 2 * act_rows || !DT_OK(dtype))
+        return MFC_EINVAL;
+    GateArgs a = {};
+    a.rows = rows; a.act_rows = act_rows; a.W = W; a.ldo = ldo; a.ldm = ldm; a.ldr = ldr; a.ldy = ldy;
+    a.o = o; a.s2 = s2; a.res = res; a.y = y; a.inv_k = inv_k;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_F32) hipLaunchKernelGGL(gate_fwd_kernel<float>, dim3(grid1d(rows * W)), dim3(AT), 0, st, a);
+    else hipLaunchKernelGGL(gate_fwd_kernel<u16>, dim3(grid1d(rows * W)), dim3(AT), 0, st, a);
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_gate_bwd(int dtype, int64_t rows, int64_t W, const void* dy, int64_t ldy, const void* o,
+                            int64_t ldo, const void* s2, int64_t ldm, float inv_k, void* dout_o, void* ds2,
+                            int64_t ldd, void* stream) {
+    if (!dy || !o || !s2 || !dout_o || !ds2) return MFC_EFAULT;
+    if (rows <= 0 || W <= 0 || !DT_OK(dtype)) return MFC_EINVAL;
+    GateArgs a = {};
+    a.rows = rows; a.W = W; a.ldo = ldo; a.ldm = ldm; a.ldy = ldy; a.ldd = ldd;
+    a.o = o; a.s2 = s2; a.dy = dy; a.dox = dout_o; a.ds2 = ds2; a.inv_k = inv_k;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_F32) hipLaunchKernelGGL(gate_bwd_kernel<float>, dim3(grid1d(rows * W)), dim3(AT), 0, st, a);
+    else hipLaunchKernelGGL(gate_bwd_kernel<u16>, dim3(grid1d(rows * W)), dim3(AT), 0, st, a);
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_copy2d(int dtype, int64_t rows, int64_t W, const void* src, int64_t lds, void* dst, int64_t ldd,
+                          float alpha, int accumulate, void* stream) {
+    if (!src || !dst) return MFC_EFAULT;
+    if (rows <= 0 || W <= 0 || lds < W || ldd < W || !DT_OK(dtype)) return MFC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_F32)
+        hipLaunchKernelGGL(copy2d_kernel<float>, dim3(grid1d(rows * W)), dim3(AT), 0, st, rows, W, (const float*)src,
+                           lds, (float*)dst, ldd, alpha, accumulate);
+    else
+        hipLaunchKernelGGL(copy2d_kernel<u16>, dim3(grid1d(rows * W)), dim3(AT), 0, st, rows, W, (const u16*)src, lds,
+                           (u16*)dst, ldd, alpha, accumulate);
+    return mfc_launch_status();
+}

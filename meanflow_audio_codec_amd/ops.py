@@ -272,3 +272,77 @@ def adamw(p, g, m, v, *, lr, wd, step, b1=0.9, b2=0.999, eps=1e-8, p_bf16=None, 
                                     g.data_ptr(), float(grad_scale), m.data_ptr(), v.data_ptr(), float(lr),
                                     float(b1), float(b2), float(eps), float(wd), int(step), _lib.stream_ptr()),
                "mfc_adamw")
+
+
+# ---------------------------------------------------------------------------
+# AdaLN / gating / strided copies (2-D views: stride(1) == 1, stride(0) = leading dimension)
+# ---------------------------------------------------------------------------
+
+
+def _v2(t):
+    assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
+    return t
+
+
+def adaln_fwd(x, scale, shift, act_rows=None, mod_div=1, out=None):
+    _v2(x), _v2(scale), _v2(shift)
+    rows, W = x.shape
+    assert scale.stride(0) == shift.stride(0) and scale.dtype == x.dtype == shift.dtype
+    if out is None:
+        out = torch.empty((rows, W), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().mfc_adaln_fwd(_lib.dtype_code(x.dtype), rows, rows if act_rows is None else act_rows, W,
+                                        x.data_ptr(), x.stride(0), scale.data_ptr(), shift.data_ptr(),
+                                        scale.stride(0), mod_div, out.data_ptr(), out.stride(0), _lib.stream_ptr()),
+               "mfc_adaln_fwd")
+    return out
+
+
+def adaln_bwd(x, scale, dy, dscale, dshift, mod_div=1, dx=None):
+    _v2(x), _v2(scale), _v2(dy), _v2(dscale), _v2(dshift)
+    rows, W = x.shape
+    assert dscale.stride(0) == dshift.stride(0)
+    if dx is None:
+        dx = torch.empty((rows, W), dtype=x.dtype, device=x.device)
+    assert dx.stride(0) == x.stride(0) or True
+    # the kernel writes dx with x's leading dimension: use a dense temp unless they agree
+    tmp = dx if dx.stride(0) == x.stride(0) else torch.empty_strided((rows, W), (x.stride(0), 1), dtype=x.dtype,
+                                                                      device=x.device)
+    _lib.check(_lib.lib().mfc_adaln_bwd(_lib.dtype_code(x.dtype), rows, W, x.data_ptr(), x.stride(0),
+                                        scale.data_ptr(), scale.stride(0), mod_div, dy.data_ptr(), dy.stride(0),
+                                        tmp.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), dscale.stride(0),
+                                        _lib.stream_ptr()), "mfc_adaln_bwd")
+    if tmp is not dx:
+        copy2d(tmp, dx)
+    return dx
+
+
+def gate_fwd(o, s2, res, inv_k, out, act_rows=None):
+    _v2(o), _v2(s2), _v2(res), _v2(out)
+    rows, W = o.shape
+    _lib.check(_lib.lib().mfc_gate_fwd(_lib.dtype_code(o.dtype), rows, rows if act_rows is None else act_rows, W,
+                                       o.data_ptr(), o.stride(0), s2.data_ptr(), s2.stride(0), res.data_ptr(),
+                                       res.stride(0), float(inv_k), out.data_ptr(), out.stride(0),
+                                       _lib.stream_ptr()), "mfc_gate_fwd")
+    return out
+
+
+def gate_bwd(dy, o, s2, inv_k, ds2, do=None):
+    _v2(dy), _v2(o), _v2(s2), _v2(ds2)
+    rows, W = o.shape
+    if do is None:
+        do = torch.empty_strided((rows, W), (o.stride(0), 1), dtype=o.dtype, device=o.device)
+    assert do.stride(0) == o.stride(0)
+    _lib.check(_lib.lib().mfc_gate_bwd(_lib.dtype_code(o.dtype), rows, W, dy.data_ptr(), dy.stride(0), o.data_ptr(),
+                                       o.stride(0), s2.data_ptr(), s2.stride(0), float(inv_k), do.data_ptr(),
+                                       ds2.data_ptr(), ds2.stride(0), _lib.stream_ptr()), "mfc_gate_bwd")
+    return do
+
+
+def copy2d(src, dst, alpha=1.0, accumulate=False):
+    _v2(src), _v2(dst)
+    assert src.shape == dst.shape and src.dtype == dst.dtype
+    rows, W = src.shape
+    _lib.check(_lib.lib().mfc_copy2d(_lib.dtype_code(src.dtype), rows, W, src.data_ptr(), src.stride(0),
+                                     dst.data_ptr(), dst.stride(0), float(alpha), int(accumulate),
+                                     _lib.stream_ptr()), "mfc_copy2d")
+    return dst
