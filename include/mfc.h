@@ -266,6 +266,11 @@ int mfc_gate_bwd(int dtype, int64_t rows, int64_t W, const void* dy, int64_t ldy
 int mfc_copy2d(int dtype, int64_t rows, int64_t W, const void* src, int64_t lds, void* dst, int64_t ldd,
                float alpha, int accumulate, void* stream);
 
+/* dst[b, c, r] = alpha * src[b, r, c] (+ add[b, c, r] if add != NULL): the token/channel transposes of
+ * MLPMixerBlock (models/mlp_mixer.py:80-84) with the residual add fused into the way back. */
+int mfc_transpose(int dtype, int64_t batch, int rows, int cols, const void* src, void* dst, float alpha,
+                  const void* add, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

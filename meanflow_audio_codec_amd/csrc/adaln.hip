@@ -167,6 +167,39 @@ __global__ void __launch_bounds__(AT) copy2d_kernel(int64_t rows, int64_t W, con
     }
 }
 
+// batched 2-D transpose: src [batch, rows, cols] -> dst [batch, cols, rows] (32x32 LDS tiles)
+template <typename T>
+__global__ void __launch_bounds__(256) transpose_kernel(int64_t batch, int rows, int cols, const T* src, T* dst,
+                                                        float alpha, const T* add) {
+    __shared__ float tile[32][33];
+    const int tilesR = (rows + 31) / 32, tilesC = (cols + 31) / 32;
+    const int64_t per = (int64_t)tilesR * tilesC, total = batch * per;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const int64_t b = t / per;
+        const int tt = (int)(t - b * per), tr = tt / tilesC, tc = tt - tr * tilesC;
+        const T* sp = src + b * (int64_t)rows * cols;
+        T* dp = dst + b * (int64_t)rows * cols;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = tr * 32 + ty + 8 * k, c = tc * 32 + tx;
+            tile[ty + 8 * k][tx] = (r < rows && c < cols) ? St<T>::ld(sp + (int64_t)r * cols + c) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = tc * 32 + ty + 8 * k, r = tr * 32 + tx;   // dst[c][r]
+            if (r < rows && c < cols) {
+                float v = alpha * tile[tx][ty + 8 * k];
+                const int64_t off = b * (int64_t)rows * cols + (int64_t)c * rows + r;
+                if (add) v += St<T>::ld(add + off);
+                St<T>::st(dp + (int64_t)c * rows + r, v);
+            }
+        }
+    }
+}
+
 inline unsigned grid1d(int64_t n) {
     int64_t b = ceil_div64(n, AT);
     return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -246,5 +279,21 @@ extern "C" int mfc_copy2d(int dtype, int64_t rows, int64_t W, const void* src, i
     else
         hipLaunchKernelGGL(copy2d_kernel<u16>, dim3(grid1d(rows * W)), dim3(AT), 0, st, rows, W, (const u16*)src, lds,
                            (u16*)dst, ldd, alpha, accumulate);
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_transpose(int dtype, int64_t batch, int rows, int cols, const void* src, void* dst, float alpha,
+                             const void* add, void* stream) {
+    if (!src || !dst) return MFC_EFAULT;
+    if (batch <= 0 || rows <= 0 || cols <= 0 || !DT_OK(dtype)) return MFC_EINVAL;
+    const int64_t tiles = batch * (int64_t)((rows + 31) / 32) * ((cols + 31) / 32);
+    const unsigned grid = (unsigned)(tiles > 16384 ? 16384 : tiles);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_F32)
+        hipLaunchKernelGGL(transpose_kernel<float>, dim3(grid), dim3(256), 0, st, batch, rows, cols, (const float*)src,
+                           (float*)dst, alpha, (const float*)add);
+    else
+        hipLaunchKernelGGL(transpose_kernel<u16>, dim3(grid), dim3(256), 0, st, batch, rows, cols, (const u16*)src,
+                           (u16*)dst, alpha, (const u16*)add);
     return mfc_launch_status();
 }

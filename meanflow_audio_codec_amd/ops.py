@@ -346,3 +346,16 @@ def copy2d(src, dst, alpha=1.0, accumulate=False):
                                      dst.data_ptr(), dst.stride(0), float(alpha), int(accumulate),
                                      _lib.stream_ptr()), "mfc_copy2d")
     return dst
+
+
+def transpose(src, batch, rows, cols, add=None, alpha=1.0, out=None):
+    """[batch, rows, cols] -> [batch, cols, rows] (+ add), contiguous buffers of batch*rows*cols elements."""
+    assert src.is_contiguous() and src.numel() == batch * rows * cols
+    if out is None:
+        out = torch.empty(src.numel(), dtype=src.dtype, device=src.device)
+    assert out.is_contiguous() and out.numel() == src.numel() and out.dtype == src.dtype
+    if add is not None:
+        assert add.is_contiguous() and add.numel() == src.numel() and add.dtype == src.dtype
+    _lib.check(_lib.lib().mfc_transpose(_lib.dtype_code(src.dtype), batch, rows, cols, src.data_ptr(), out.data_ptr(),
+                                        float(alpha), _lib.ptr(add), _lib.stream_ptr()), "mfc_transpose")
+    return out

@@ -218,6 +218,80 @@ def mlp_flow_shapes(D, cond_dim, latent_dim, num_blocks):
 
 
 # --------------------------------------------------------------------------
+# MLP-Mixer flow and encoder (models/mlp_mixer.py)
+# --------------------------------------------------------------------------
+
+
+def mixer_block(p, x, cond):
+    """MLPMixerBlock.__call__, models/mlp_mixer.py:66-94 (x: [B, tokens, channels]); AdaLN :27-45."""
+    C = x.shape[-1]
+
+    def adaln(v, d):
+        ss = dense(d, cond)
+        return (1.0 + ss[:, None, :C]) * layer_norm(v) + ss[:, None, C:]
+
+    res = x
+    a = adaln(x, p["Dense_0"]).transpose(1, 2)
+    a = dense(p["Dense_2"], gelu(dense(p["Dense_1"], a))).transpose(1, 2)
+    x = a + res
+    res = x
+    a = adaln(x, p["Dense_3"])
+    a = dense(p["Dense_5"], gelu(dense(p["Dense_4"], a)))
+    return a + res
+
+
+def mixer_flow_apply(params, x, time, latents=None):
+    """ConditionalMLPMixerFlow.__call__ / ConditionalMLPMixerBlock, models/mlp_mixer.py:137-163,205-235."""
+    cd = params["blocks_0"]["mixer_block"]["Dense_0"]["kernel"].shape[0]
+    cond = sinusoidal_embedding(time[:, 0], cd) + sinusoidal_embedding(time[:, 1], cd)
+    if latents is not None:
+        cond = cond + dense(params["latent_proj"], latents.reshape(latents.shape[0], -1))
+    nb = sum(1 for k in params if k.startswith("blocks_"))
+    B = x.shape[0]
+    for i in range(nb):
+        p = params[f"blocks_{i}"]
+        C = p["mixer_block"]["Dense_0"]["kernel"].shape[1] // 2
+        h = dense(p["input_proj"], x).reshape(B, -1, C)
+        h = mixer_block(p["mixer_block"], h, cond)
+        x = dense(p["output_proj"], h.reshape(B, -1)) / nb + x
+    return x
+
+
+def mixer_encode(params, x):
+    """MLPMixerEncoder.__call__, models/mlp_mixer.py:281-323 -> [B, num_latent_tokens, latent_dim]."""
+    p = params["encoder"]
+    n_lat, L = p["latent_queries"].shape
+    B = x.shape[0]
+    ctx = dense(p["input_proj"], x).reshape(B, -1, L)
+    n_ctx = ctx.shape[1]
+    allt = torch.cat([ctx, p["latent_queries"][None].expand(B, n_lat, L)], dim=1)
+    cond = p["condition_emb"][None].expand(B, L)
+    return mixer_block(p["mixer_block"], allt, cond)[:, n_ctx:, :]
+
+
+def _mixer_block_shapes(nt, C, cond_dim, tmd, cmd):
+    return {"Dense_0": {"kernel": (cond_dim, 2 * C), "bias": (2 * C,)},
+            "Dense_1": {"kernel": (nt, tmd), "bias": (tmd,)}, "Dense_2": {"kernel": (tmd, nt), "bias": (nt,)},
+            "Dense_3": {"kernel": (cond_dim, 2 * C), "bias": (2 * C,)},
+            "Dense_4": {"kernel": (C, cmd), "bias": (cmd,)}, "Dense_5": {"kernel": (cmd, C), "bias": (C,)}}
+
+
+def mixer_flow_shapes(D, cond_dim, latent_dim, num_blocks, C=16, tmd=2048, cmd=2048, n_lat=32, n_ctx=512):
+    s = int(math.sqrt(D))
+    nt = s * s
+    tree = {}
+    for i in range(num_blocks):
+        tree[f"blocks_{i}"] = {"input_proj": {"kernel": (D, nt * C), "bias": (nt * C,)},
+                               "mixer_block": _mixer_block_shapes(nt, C, cond_dim, tmd, cmd),
+                               "output_proj": {"kernel": (nt * C, D), "bias": (D,)}}
+    tree["latent_proj"] = {"kernel": (n_lat * latent_dim, cond_dim), "bias": (cond_dim,)}
+    tree["encoder"] = {"input_proj": {"kernel": (D, n_ctx * latent_dim), "bias": (n_ctx * latent_dim,)},
+                       "latent_queries": (n_lat, latent_dim), "condition_emb": (latent_dim,),
+                       "mixer_block": _mixer_block_shapes(n_ctx + n_lat, latent_dim, latent_dim, tmd, cmd)}
+    return tree
+
+
+# --------------------------------------------------------------------------
 # parameter helpers
 # --------------------------------------------------------------------------
 
@@ -239,8 +313,11 @@ def init_params(shapes, seed=0, dtype=torch.float64, special=True):
         if special:
             if name == "layer_scale_gamma":
                 return torch.full(shape, 1e-6, dtype=dtype)
+            if name in ("latent_queries", "condition_emb"):     # nn.initializers.normal(0.02), mlp_mixer.py:261-273
+                return 0.02 * torch.randn(shape, generator=g, dtype=dtype)
             return torch.zeros(shape, dtype=dtype)
-        scale = {"bias": 0.1, "gamma": 0.5, "beta": 0.1, "layer_scale_gamma": 0.5}[name]
+        scale = {"bias": 0.1, "gamma": 0.5, "beta": 0.1, "layer_scale_gamma": 0.5, "latent_queries": 0.5,
+                 "condition_emb": 0.5}[name]
         return scale * torch.randn(shape, generator=g, dtype=dtype)
 
     return rec(shapes, "")
