@@ -13,7 +13,15 @@ import torch
 
 from oracle import flow_oracle as fo
 
-torch.set_default_dtype(torch.float64)
+
+
+@pytest.fixture(autouse=True)
+def _float64_default():
+    """the oracle runs in float64; restore the process default afterwards (other test modules rely on fp32)"""
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(old)
 
 
 def _mlp_params(noise, cond=32, latent=64, blocks=2, seed=0):
