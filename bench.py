@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--decode-batch", type=int, default=None)
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (no roofline)")
+    ap.add_argument("--no-overlap", action="store_true", help="reference order: loss -> all-reduce -> AdamW")
     return ap.parse_args()
 
 
@@ -259,7 +261,7 @@ def main():
     def one_step(state, key):
         tokens = tok.tokenize(clips)
         return train_step(state, key, tokens.reshape(B, -1), strat, reducer=reducer, row0=rank * B,
-                          global_batch=world * B)
+                          global_batch=world * B, overlap=not args.no_overlap)
 
     def barrier():
         if world > 1:
@@ -272,7 +274,8 @@ def main():
         torch.cuda.synchronize()
         log(f"warm-up step {i} done; peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     barrier()
-    _lib.enable_timing()
+    if not args.no_kernel_timing:
+        _lib.enable_timing()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         state, loss, key = one_step(state, key)
@@ -312,6 +315,8 @@ def main():
                 dom["share_of_step"] = round(row["per_step_ms"] / ms_per_step, 4)
                 break
         out["roofline"] = dom
+        out["sum_kernel_ms_per_step"] = round(sum(r["per_step_ms"] for r in rows), 2)
+        out["launches_per_step"] = int(sum(r["launches"] for r in rows) / max(1, args.steps))
         out["top_kernels"] = [
             dict(kernel=kernel_of(r["name"], r["ints"]), per_step_ms=round(r["per_step_ms"], 3),
                  launches=r["launches"], avg_ms=round(r["avg_ms"], 4),

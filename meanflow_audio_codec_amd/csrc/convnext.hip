@@ -27,6 +27,7 @@
 // and per-row statistics accumulate in registers and are flushed with a few
 // atomics per workgroup (not per tile).
 #include "mfc_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -382,6 +383,7 @@ struct FwdArgs {
     float* S1; float* S2;          // stats mode
     const float* q; const float* qd;  // apply mode
     void* o; void* od;
+    int dbg;   // profiling ablations only (env MFC_CNX_DBG): 1 = skip the MFMA chain, 2 = stage only the first tile
 };
 
 template <typename T, bool JVP>
@@ -457,12 +459,12 @@ cnx_fwd_kernel(FwdArgs a) {
             }
             __syncthreads();
         }
-        halo_commit<T, JVP>(l, raw);
+        if (!(a.dbg & 2) || t == t0) halo_commit<T, JVP>(l, raw);
         __syncthreads();
-        if (t + 1 < t1) { const TileCoord c = tile_coord(a.geo, t + 1); halo_load<T, JVP>(raw, h0, h0d, c.r, s, c.y0, c.x0); }
+        if (t + 1 < t1 && !(a.dbg & 2)) { const TileCoord c = tile_coord(a.geo, t + 1); halo_load<T, JVP>(raw, h0, h0d, c.r, s, c.y0, c.x0); }
         const int gx = x0 + m;
 #pragma unroll 1
-        for (int ri = 0; ri < RPW; ++ri) {
+        for (int ri = 0; ri < ((a.dbg & 1) ? 0 : RPW); ++ri) {
             const int y = wave * RPW + ri;
             const int gy = y0 + y;
             const bool ok = gy < s && gx < s;
@@ -970,6 +972,8 @@ int fwd_common(int dtype, int mode, int64_t R, int s, const void* h0, const void
     a.geo = make_geo(R, s, MAX_BLOCKS, grid);
     a.h0 = h0; a.h0d = h0dot; a.sc = scale; a.sh = shift; a.scd = scaledot; a.shd = shiftdot;
     a.p = to_dev(p); a.S1 = S1; a.S2 = S2; a.q = q; a.qd = qdot; a.o = o; a.od = odot;
+    static const int dbg = getenv("MFC_CNX_DBG") ? atoi(getenv("MFC_CNX_DBG")) : 0;
+    a.dbg = dbg;
     hipStream_t st = (hipStream_t)stream;
     return dtype == MFC_F32 ? fwd_launch<float>(jvp, mode, a, grid, st) : fwd_launch<u16>(jvp, mode, a, grid, st);
 }

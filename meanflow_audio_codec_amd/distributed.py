@@ -23,6 +23,31 @@ class GradReducer:
         self.world = dist.get_world_size(group)
         self._flat = None
 
+    def reduce_tensors(self, tensors) -> None:
+        """SUM all-reduce a list of gradient tensors in place on the CURRENT stream (one block of the
+        reverse pass): big ones individually, the small fp32 ones packed into one flat bucket."""
+        if self.world == 1:
+            return
+        small = [t for t in tensors if t.numel() <= self.small_numel and t.dtype == torch.float32]
+        ids = {id(t) for t in small}
+        for t in tensors:
+            if id(t) not in ids:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        if small:
+            flat = torch.cat([t.reshape(-1) for t in small])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            off = 0
+            for t in small:
+                t.reshape(-1).copy_(flat[off:off + t.numel()])
+                off += t.numel()
+
+    def reduce_scalar(self, loss: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return loss
+        out = loss.detach().clone().to(torch.float32)
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+        return out
+
     def reduce(self, grads: dict, loss: torch.Tensor) -> torch.Tensor:
         if self.world == 1:
             return loss

@@ -61,6 +61,7 @@ class ConditionalConvFlow:
         self.latent_input_dim = latent_dimension if latent_input_dim is None else latent_input_dim
         self.dtype = dtype
         self._ws = {}
+        self._block_names = [self.block_param_names(i) for i in range(num_blocks)]
 
     # ------------------------------------------------------------------ params
     def param_shapes(self) -> dict:
@@ -220,8 +221,13 @@ class ConditionalConvFlow:
         outdot = X[R:] if n_tan else None
         return out, outdot, ctx
 
-    def backward(self, w: dict, ctx: ConvCtx, dout: torch.Tensor, grads: dict):
-        """Reverse pass through the saved primal.  Writes every block parameter's gradient into
+    def block_param_names(self, i: int) -> list:
+        pre = f"blocks_{i}/"
+        return [k for k in self.param_shapes() if k.startswith(pre)]
+
+    def backward(self, w: dict, ctx: ConvCtx, dout: torch.Tensor, grads: dict, on_block=None):
+        """Reverse pass through the saved primal.  ``on_block(names)`` is called as soon as the gradients
+        of one block are complete (lets the caller overlap the exchange / AdamW with the rest of the pass).  Writes every block parameter's gradient into
         ``grads`` (big kernels: overwritten in the model dtype; small fp32 leaves: overwritten too).
         Returns (dx [R,D], dcond [R,cond] fp32)."""
         R, K, S, s, T = ctx.R, self.num_blocks, self.S, self.spatial_size, self.dtype
@@ -263,6 +269,8 @@ class ConditionalConvFlow:
             dense_dw(x_in, da1, out=grads[f"{b}/input_proj1/kernel"])
             ops.colsum(da1, out=grads[f"{b}/input_proj1/bias"])
             dX = dense_dx(da1, w[f"{b}/input_proj1/kernel"], residual=dX, beta=1.0)
+            if on_block is not None:
+                on_block(self._block_names[i])
         return dX, dcond, None
 
     def backward_conditioning(self, w: dict, ctx: ConvCtx, dcond: torch.Tensor, latents, grads: dict, dlat=None):

@@ -127,7 +127,7 @@ class ConditionalFlow:
             ops.copy2d(XC[R:, L:], outdot)
         return out, outdot, (ctx if save else None)
 
-    def backward(self, w: dict, ctx: MlpCtx, dout, grads: dict):
+    def backward(self, w: dict, ctx: MlpCtx, dout, grads: dict, on_block=None):
         R, K, T = ctx.R, self.num_blocks, self.dtype
         D, L, I, dev = self.noise_dimension, self.latent_dimension, self.input_dimension, dout.device
         dXC = torch.zeros((R, I), dtype=T, device=dev)
@@ -162,6 +162,8 @@ class ConditionalFlow:
             ops.colsum(dac, out=grads[f"{b}/conditioning_layer/dense1/bias"])
             dcond = dense_dx(dac, w[f"{b}/conditioning_layer/dense1/kernel"], residual=dcond, beta=1.0)
             dXC = dXCi
+            if on_block is not None:
+                on_block([k for k in grads if k.startswith(b + "/")])
         ops.copy2d(dXC[:, :L], dlat, accumulate=True)
         dx = torch.empty((R, D), dtype=T, device=dev)
         ops.copy2d(dXC[:, L:], dx)

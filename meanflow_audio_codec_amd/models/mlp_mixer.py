@@ -203,7 +203,7 @@ class ConditionalMLPMixerFlow:
             X = Xn
         return X[:R], (X[R:] if n_tan else None), (ctx if save else None)
 
-    def backward(self, w: dict, ctx: MixerCtx, dout, grads: dict):
+    def backward(self, w: dict, ctx: MixerCtx, dout, grads: dict, on_block=None):
         R, K, nt, C = ctx.R, self.num_blocks, self.num_tokens, self.num_channels
         dX = dout
         dcond = torch.zeros((R, self.condition_dimension), dtype=torch.float32, device=dout.device)
@@ -220,6 +220,8 @@ class ConditionalMLPMixerFlow:
             dense_dw(X, dP, out=grads[f"{b}/input_proj/kernel"])
             ops.colsum(dP, out=grads[f"{b}/input_proj/bias"])
             dX = dense_dx(dP, w[f"{b}/input_proj/kernel"], residual=dX, beta=1.0)
+            if on_block is not None:
+                on_block([k for k in grads if k.startswith(b + "/")])
         return dX, dcond, None
 
     def backward_conditioning(self, w: dict, ctx: MixerCtx, dcond, latents, grads: dict, dlat=None):

@@ -79,6 +79,18 @@ class TrainState:
             self._grads = g
         return self._grads
 
+    def begin_update(self):
+        """Start one optimizer step whose leaves are updated piecewise with ``apply_subset``."""
+        self.step += 1
+
+    def apply_subset(self, names, grads: dict, grad_scale: float = 1.0):
+        tx = self.tx
+        for k in names:
+            p, g, w = self.params[k], grads[k], self.work[k]
+            ops.adamw(p, g, self.opt_state["mu"][k], self.opt_state["nu"][k], lr=tx.learning_rate,
+                      wd=tx.weight_decay, step=self.step, b1=tx.b1, b2=tx.b2, eps=tx.eps,
+                      p_bf16=(w if w.dtype == torch.bfloat16 else None), grad_scale=grad_scale)
+
     def apply_gradients(self, *, grads: dict, grad_scale: float = 1.0):
         self.step += 1
         tx = self.tx

@@ -1,27 +1,75 @@
 """train_step -- host mirror of ``trainers/training_steps.py:15-61``.
 
 ``train_step(state, key, x, loss_strategy) -> (state, loss, key)``; the returned key is ADVANCED
-(reference defect 4: it returned the key unchanged, so every step reused the same noise).  With
-``torch.distributed`` initialised the gradients are summed across ranks (RCCL over xGMI) between
-``compute_loss`` and ``apply_gradients`` -- the reference has no distributed path.
+(reference defect 4: it returned the key unchanged, so every step reused the same noise).
+
+Two schedules of the same arithmetic:
+
+* ``overlap=False``: the reference's order -- ``compute_loss`` then (gradient all-reduce) then
+  ``apply_gradients`` (``trainers/training_steps.py:32-33``).
+* ``overlap=True`` (default): as soon as the reverse pass has finished one block, that block's gradients
+  are (all-reduced over RCCL and) fed to the fused AdamW kernel on a SIDE HIP stream while the main
+  stream continues the reverse pass of the earlier blocks.  AdamW is HBM-bound and the reverse-pass
+  kernels are not, so the two streams overlap well on one GPU; with data parallelism the gradient
+  exchange of block i hides behind the compute of blocks i-1..0.  Results are identical (every leaf
+  still gets exactly one update from its final gradient).
 """
 from __future__ import annotations
 
+import torch
+
 from .loss_strategies import FlowMatchingLoss, LossStrategy
+
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _side_streams[device] = s
+    return s
 
 
 def _train_step_with_strategy(state, key, x, loss_strategy: LossStrategy, *, reducer=None, row0=0,
-                              global_batch=None):
-    loss, grads = loss_strategy.compute_loss(state, key, x, row0=row0, global_batch=global_batch)
+                              global_batch=None, overlap=True):
+    if not overlap or not x.is_cuda:
+        loss, grads = loss_strategy.compute_loss(state, key, x, row0=row0, global_batch=global_batch)
+        if reducer is not None:
+            loss = reducer.reduce(grads, loss)
+        state = state.apply_gradients(grads=grads)
+        return state, loss, key.next()
+
+    main = torch.cuda.current_stream(x.device)
+    side = _side_stream(x.device)
+    side.wait_stream(main)                 # previous step fully issued before the side stream reuses buffers
+    state.begin_update()
+    done = set()
+    grads_ref = state.grad_buffers()
+
+    def on_block(names):
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            if reducer is not None:
+                reducer.reduce_tensors([grads_ref[n] for n in names])
+            state.apply_subset(names, grads_ref)
+        done.update(names)
+
+    loss, grads = loss_strategy.compute_loss(state, key, x, row0=row0, global_batch=global_batch, on_block=on_block)
+    rest = [k for k in state.params if k not in done]
+    if rest:
+        on_block(rest)
     if reducer is not None:
-        loss = reducer.reduce(grads, loss)
-    state = state.apply_gradients(grads=grads)
+        loss = reducer.reduce_scalar(loss)
+    main.wait_stream(side)                 # the next forward reads the updated weights
     return state, loss, key.next()
 
 
 def train_step(state, key, x, loss_strategy: LossStrategy | None = None, *, reducer=None, row0=0,
-               global_batch=None):
+               global_batch=None, overlap=True):
     if loss_strategy is None:
         loss_strategy = FlowMatchingLoss()
     return _train_step_with_strategy(state, key, x, loss_strategy, reducer=reducer, row0=row0,
-                                     global_batch=global_batch)
+                                     global_batch=global_batch, overlap=overlap)

@@ -165,3 +165,23 @@ def test_data_parallel_shards_sum_to_global_batch():
     for k in full:
         if full[k].abs().max() > 0:
             assert ((acc[k] - full[k]).abs().max() / full[k].abs().max()).item() < 2e-3, k
+
+
+def test_overlapped_train_step_matches_sequential():
+    """overlap=True (per-block AdamW on a side stream during the reverse pass) == overlap=False (up to the
+    run-to-run noise of the fp32-atomic small-parameter gradients)."""
+    from meanflow_audio_codec_amd.trainers import ImprovedMeanFlowLoss, PRNGKey, train_step
+    results = []
+    for overlap in (False, True):
+        model, state, pq = _make(torch.float32, seed=21)
+        x, e, t, r = _draws(4, seed=22)
+        key = PRNGKey(5)
+        for _ in range(3):
+            state, loss, key = train_step(state, key, x.cuda(), ImprovedMeanFlowLoss(), overlap=overlap)
+        torch.cuda.synchronize()
+        results.append(({k: v.clone() for k, v in state.params.items()}, loss.item(), state.step))
+    (pa, la, sa), (pb, lb, sb) = results
+    assert sa == sb == 3 and abs(la - lb) < 1e-6
+    for k in pa:
+        d = (pa[k] - pb[k]).abs()
+        assert (d > 1e-5).float().mean().item() < 1e-3, (k, d.max().item())

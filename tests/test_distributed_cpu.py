@@ -41,6 +41,12 @@ def _worker(rank, world, port, q):
             tol = 1e-5 if v.dtype == torch.float32 else 5e-2
             assert (grads[k].float() - want).abs().max() <= tol * max(1.0, want.abs().max().item()), k
         assert abs(total.item() - 0.25 * sum(range(1, world + 1))) < 1e-6
+        # per-block entry points used by the overlapped train_step
+        blk = {k: v.clone() for k, v in ref.items()}
+        red.reduce_tensors(list(blk.values()))
+        for k in blk:
+            assert torch.equal(blk[k], grads[k]), k
+        assert abs(red.reduce_scalar(loss).item() - total.item()) < 1e-6
         # second call reuses the flat bucket
         total2 = red.reduce({k: v.clone() for k, v in ref.items()}, loss)
         assert abs(total2.item() - total.item()) < 1e-6
