@@ -321,7 +321,7 @@ def main():
             dict(kernel=kernel_of(r["name"], r["ints"]), per_step_ms=round(r["per_step_ms"], 3),
                  launches=r["launches"], avg_ms=round(r["avg_ms"], 4),
                  **({k: v for k, v in (roofline_of(r, args.dtype) or {}).items() if k in ("bound", "frac")}))
-            for r in rows[:12]]
+            for r in rows[:40]]
         flops_alg = 4.0 * conv_flow_flops_fwd(D, wl["blocks"], wl["cond"])
         out["step_model"] = {"algorithmic_gflop_per_sample": round(flops_alg / 1e9, 2),
                              "achieved_tflops_algorithmic": round(flops_alg * value / world / 1e12, 2)}

@@ -536,10 +536,17 @@ struct BwdArgs {
 // lane (q, r): elements (pixel 4q+i, channel r)
 template <typename T>
 __device__ inline typename Frag<T>::type pix_k_frag(const T* tile, int q, int r) {
-    typename Frag<T>::type f;
-    const T* p = tile + (4 * q) * CS + r;
-    frag_raw(f, p[0], p[CS], p[2 * CS], p[3 * CS]);
-    return f;
+    if constexpr (sizeof(T) == 2) {
+        // gfx950 LDS transpose read: one instruction fetches the 4(pixel) x 16(channel) block of lane
+        // group q column-major -- lane 4q'+p supplies the address of pixel 4q+q', channels 4p..4p+3
+        const T* p = tile + (4 * q + (r >> 2)) * CS + 4 * (r & 3);
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+    } else {
+        typename Frag<T>::type f;
+        const T* p = tile + (4 * q) * CS + r;
+        frag_raw(f, p[0], p[CS], p[2 * CS], p[3 * CS]);
+        return f;
+    }
 }
 
 // MODE 0: dq[r,ch] = sum dy*g1, dbeta += sum dy.

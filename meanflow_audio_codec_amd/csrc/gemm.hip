@@ -38,6 +38,7 @@ struct GemmArgs {
     float* ws;       // split-K workspace (fp32 [M,N]) or null
     int vecA, vecB;  // 16-byte vector loads legal
     int vecC;        // 16-byte row-contiguous C (and R) accesses legal
+    int m_fast;      // blockIdx.x walks M tiles (else N tiles)
 };
 
 template <typename T> struct Vec;   // 16-byte global vector
@@ -153,8 +154,10 @@ gemm_kernel(GemmArgs g) {
 
     const T* A = (const T*)g.A;
     const T* B = (const T*)g.B;
-    const int64_t m0 = (int64_t)blockIdx.y * BM;
-    const int64_t n0 = (int64_t)blockIdx.x * BN;
+    // M-tile index fastest when it fits: the M-tiles of one N-tile run back to back, so the streamed
+    // weight tile is fetched from HBM once and re-read from L2 / Infinity Cache
+    const int64_t m0 = (int64_t)(g.m_fast ? blockIdx.x : blockIdx.y) * BM;
+    const int64_t n0 = (int64_t)(g.m_fast ? blockIdx.y : blockIdx.x) * BN;
     const int64_t kbeg = (int64_t)blockIdx.z * g.kchunk;
     const int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
 
@@ -335,8 +338,11 @@ void launch_bk(bool ta, bool tb, dim3 grid, const GemmArgs& g, hipStream_t st) {
 }
 
 template <typename T>
-int launch(int flags, const GemmArgs& g, int bk, int splitk, int gelu, int64_t act_rows, hipStream_t st) {
-    dim3 grid((unsigned)ceil_div64(g.N, BN), (unsigned)ceil_div64(g.M, BM), (unsigned)splitk);
+int launch(int flags, GemmArgs g, int bk, int splitk, int gelu, int64_t act_rows, hipStream_t st) {
+    const int64_t tm = ceil_div64(g.M, BM), tn = ceil_div64(g.N, BN);
+    g.m_fast = (tn <= 65535) ? 1 : 0;
+    if (!g.m_fast && tm > 65535) return MFC_EINVAL;
+    dim3 grid((unsigned)(g.m_fast ? tm : tn), (unsigned)(g.m_fast ? tn : tm), (unsigned)splitk);
     const bool ta = flags & MFC_GEMM_TRANS_A, tb = flags & MFC_GEMM_TRANS_B;
     if (bk == 32) launch_bk<T, 32>(ta, tb, grid, g, st);
     else launch_bk<T, 64>(ta, tb, grid, g, st);
@@ -371,7 +377,7 @@ extern "C" int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
     if (splitk < 1) splitk = 1;
     if ((splitk > 1 || gelu) && !ws) return MFC_EINVAL;
     if (gelu && (act_rows <= 0 || act_rows > M)) return MFC_EINVAL;
-    if (ceil_div64(M, BM) > 65535 || splitk > 65535) return MFC_EINVAL;
+    if (splitk > 65535) return MFC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const size_t es = dtype == MFC_F32 ? 4 : 2;
 
