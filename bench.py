@@ -104,6 +104,28 @@ def algorithmic_work(name, ints, nn):
     return None
 
 
+def traffic_key(name, ints):
+    if name == "mfc_adamw":
+        return f"adamw_kernel n={ints[1]}"
+    if name == "mfc_gemm":
+        return f"gemm M={ints[2]} N={ints[3]} K={ints[4]}"
+    if name.startswith("mfc_cnx_"):
+        k = name.replace("mfc_", "")
+        k = {"cnx_bwd_main": "cnx_bwd_main_kernel"}.get(k, k + "_kernel")
+        return f"{k} R={ints[1]}"
+    return None
+
+
+def measured_traffic(name, ints):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            tab = json.load(f)
+        return tab.get(traffic_key(name, ints))
+    except Exception:
+        return None
+
+
 def kernel_of(name, ints):
     if name == "mfc_gemm":
         dt, flags, M, N, K = ints[:5]
@@ -134,18 +156,19 @@ def roofline_of(row, dtype_name):
     if w is None:
         return None
     nbytes, flops, dt = w
+    traffic = measured_traffic(row["name"], row["ints"])
     dur = row["avg_ms"] * 1e-3
     peak_f = MFMA_PEAK["f32" if dt == 0 else "bf16"]
     t_h, t_f = nbytes / HBM_PEAK, flops / peak_f
     if t_h >= t_f:
         ach = nbytes / dur / 1e9
         return dict(kernel=kernel_of(row["name"], row["ints"]), bound="hbm", achieved=round(ach, 1),
-                    peak=HBM_PEAK / 1e9, unit="GB/s", frac=round(ach / (HBM_PEAK / 1e9), 4), traffic=None,
+                    peak=HBM_PEAK / 1e9, unit="GB/s", frac=round(ach / (HBM_PEAK / 1e9), 4), traffic=traffic,
                     algorithmic_bytes=int(nbytes), algorithmic_flops=float(flops),
                     avg_launch_ms=round(row["avg_ms"], 4), launches_per_step=row["launches"])
     ach = flops / dur / 1e12
     return dict(kernel=kernel_of(row["name"], row["ints"]), bound="mfma", achieved=round(ach, 2),
-                peak=peak_f / 1e12, unit="TFLOP/s", frac=round(ach / (peak_f / 1e12), 4), traffic=None,
+                peak=peak_f / 1e12, unit="TFLOP/s", frac=round(ach / (peak_f / 1e12), 4), traffic=traffic,
                 algorithmic_bytes=int(nbytes), algorithmic_flops=float(flops),
                 avg_launch_ms=round(row["avg_ms"], 4), launches_per_step=row["launches"])
 
