@@ -243,11 +243,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     import torch.distributed as dist
+    # test hook: MFC_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and MFC_DIST_BACKEND=gloo swaps RCCL for
+    # gloo, so the multi-process path can be rehearsed on a one-GPU box (the driver never sets these)
+    if os.environ.get("MFC_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("MFC_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from meanflow_audio_codec_amd import _build, _lib
     if not _lib.LIB_PATH.exists():
