@@ -79,10 +79,10 @@ def algorithmic_work(name, ints, nn):
         px = R * s * s
         conv, exp, con = 2 * 9 * 16 * 16, 2 * 16 * 32, 2 * 32 * 16
         if name == "mfc_cnx_stats":
-            j = 2 if nn[1] else 1
+            j = 2 if nn[2] else 1
             return es * px * 16 * j, float(px) * (conv + exp) * j, dt
         if name == "mfc_cnx_apply":
-            j = 2 if nn[1] else 1
+            j = 2 if nn[2] else 1
             return es * px * 16 * 2 * j, float(px) * (conv + exp + con) * j, dt
         if name == "mfc_cnx_bwd_stats":
             return es * px * 16 * 2, float(px) * (conv + exp + con), dt

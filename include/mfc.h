@@ -80,6 +80,10 @@ int mfc_mdct_inv(const float* X, int64_t B, int64_t n_frames, int N, int hop,
 #define MFC_GEMM_GELU 8      /* tanh-GELU on rows < act_rows; rows >= act_rows
                                 are tangents: t * gelu'(pre) with pre taken
                                 from row (r - act_rows) of the SAME product   */
+#define MFC_GEMM_LN16 16     /* rows < bias_rows: LayerNorm (no affine, eps 1e-6) over every aligned
+                                group of 16 output columns (one NHWC pixel of the ConvNeXt map);
+                                1/sigma of each group goes to ln_rstd[row*(N/16) + group].  Needs
+                                N % 16 == 0, 16-byte aligned C, no split-K.                    */
 
 /* C[M,N] = alpha * (op(A)[M,K] . op(B)[K,N] + bias[N] on rows < bias_rows)
  *          + beta_res * R[M,N]
@@ -94,7 +98,7 @@ int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
              void* C, int64_t ldc,
              const float* bias, int64_t bias_rows, int64_t act_rows,
              float alpha, const void* R, int64_t ldr, float beta_res,
-             int splitk, float* ws, void* stream);
+             int splitk, float* ws, float* ln_rstd, void* stream);
 
 /* ------------------------------------------------------------------ */
 /* ConvNeXt block interior (models/conv_flow.py:65-115,162-186)        */
@@ -102,7 +106,9 @@ int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
 /* The spatial part of ConditionalConvNeXtBlock, between input_proj2 and
  * output_proj1, on NHWC maps h0 [R, s, s, 16] (R = rows of the row-stacked
  * batch; channel count C = min(16, cond/4) = 16 for every shipped config,
- * other C -> MFC_ENOSYS):
+ * other C -> MFC_ENOSYS).  The kernels take h1 = LN_C(h0) (produced by mfc_gemm's MFC_GEMM_LN16
+ * epilogue or mfc_ln16_fwd) and rho0 = 1/sqrt(var+eps) per pixel [R, s*s] fp32 (needed only together
+ * with a tangent h0dot -- the RAW tangent of h0 -- and by mfc_cnx_bwd_conv):
  *   h2 = (1+scale) * LN_C(h0) + shift                 conv_flow.py:181-186
  *   c1 = Conv3x3_SAME(h2) ; n1 = LN_C(c1)             conv_flow.py:74-84
  *   g1 = gelu(Conv1x1_{16->32}(n1))                   conv_flow.py:87-88
@@ -134,7 +140,7 @@ typedef struct {
 /* pass 1: S1[r,ch] += sum_hw g1^2 ; S2[r,ch] += sum_hw g1*g1dot (if h0dot).
  * scale/shift (and their tangents) are fp32 [R,16]; S1/S2 fp32 [R,32] must be
  * zeroed by the caller. */
-int mfc_cnx_stats(int dtype, int64_t R, int s, const void* h0, const void* h0dot,
+int mfc_cnx_stats(int dtype, int64_t R, int s, const void* h1, const float* rho0, const void* h0dot,
                   const float* scale, const float* shift, const float* scaledot, const float* shiftdot,
                   const mfc_cnx_params* p, float* S1, float* S2, void* stream);
 
@@ -144,7 +150,7 @@ int mfc_grn_finalize(int64_t R, const float* S1, const float* S2, float* G, floa
                      void* stream);
 
 /* pass 2: o (and odot) [R,s,s,16] dtype. */
-int mfc_cnx_apply(int dtype, int64_t R, int s, const void* h0, const void* h0dot,
+int mfc_cnx_apply(int dtype, int64_t R, int s, const void* h1, const float* rho0, const void* h0dot,
                   const float* scale, const float* shift, const float* scaledot, const float* shiftdot,
                   const mfc_cnx_params* p, const float* q, const float* qdot,
                   void* o, void* odot, void* stream);
@@ -165,9 +171,14 @@ int mfc_cnx_bwd_main(int dtype, int64_t R, int s, const void* h0, const float* s
 
 /* backward pass 3: dh0 = LN/FiLM-backward(conv3x3^T(dc1) + dout); conv_w
  * gradient; dscale/dshift [R,16] fp32 (+=, zeroed by caller). */
-int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, const float* scale, const float* shift,
-                     const mfc_cnx_params* p, const void* dc1, const void* dout,
+int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h1, const float* rho0, const float* scale,
+                     const float* shift, const mfc_cnx_params* p, const void* dc1, const void* dout,
                      void* dh0, const mfc_cnx_grads* g, float* dscale, float* dshift, void* stream);
+
+/* First LayerNorm of the block (conv_flow.py:181, nn.LayerNorm over the 16 channels of each pixel):
+ * y = LN_16(x) [n_pixels,16] dtype, rstd[n_pixels] fp32 (may be NULL).  The hot path fuses this into the
+ * producing product (mfc_gemm flag MFC_GEMM_LN16); this entry point is the standalone form. */
+int mfc_ln16_fwd(int dtype, int64_t n_pixels, const void* x, void* y, float* rstd, void* stream);
 
 /* ------------------------------------------------------------------ */
 /* Loss-step element-wise kernels                                      */

@@ -17,7 +17,7 @@ LIB_PATH = _HERE / "csrc" / "libmfc.so"
 HEADER = _HERE.parent / "include" / "mfc.h"
 
 MFC_F32, MFC_BF16 = 0, 1
-GEMM_TRANS_A, GEMM_TRANS_B, GEMM_ACCUM, GEMM_GELU = 1, 2, 4, 8
+GEMM_TRANS_A, GEMM_TRANS_B, GEMM_ACCUM, GEMM_GELU, GEMM_LN16 = 1, 2, 4, 8, 16
 
 _ERR = {-22: "MFC_EINVAL (bad shape/argument)", -38: "MFC_ENOSYS (unsupported)",
         -14: "MFC_EFAULT (null pointer)", -5: "MFC_EHIP (HIP launch error)"}
@@ -40,14 +40,15 @@ SIGNATURES = {
     "mfc_mdct_fwd": (c_int, [_P, c_int64, c_int64, c_int64, c_int, c_int, _P, _P]),
     "mfc_mdct_inv": (c_int, [_P, c_int64, c_int64, c_int, c_int, _P, c_int64, _P]),
     "mfc_gemm": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64,
-                         _P, c_int64, c_int64, c_float, _P, c_int64, c_float, c_int, _P, _P]),
-    "mfc_cnx_stats": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                         _P, c_int64, c_int64, c_float, _P, c_int64, c_float, c_int, _P, _P, _P]),
+    "mfc_ln16_fwd": (c_int, [c_int, c_int64, _P, _P, _P, _P]),
+    "mfc_cnx_stats": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_grn_finalize": (c_int, [c_int64, _P, _P, _P, _P, _P, _P]),
-    "mfc_cnx_apply": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_cnx_apply": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_cnx_bwd_stats": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_grn_bwd_finalize": (c_int, [c_int64, _P, _P, _P, _P, _P]),
     "mfc_cnx_bwd_main": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "mfc_cnx_bwd_conv": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_cnx_bwd_conv": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_adaln_fwd": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, _P]),
     "mfc_adaln_bwd": (c_int, [c_int, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int64, _P, c_int64, _P, _P, _P,
                               c_int64, _P]),

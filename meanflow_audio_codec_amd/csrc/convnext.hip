@@ -6,6 +6,9 @@
 //   y  = GRN(g1) = g1 (gamma + q) + beta                conv_flow.py:22-45
 //   o  = Conv1x1(y) [32->16] * layer_scale + h2         conv_flow.py:95-115
 //
+// The first LayerNorm is fused into the producing GEMM's epilogue (mfc_gemm MFC_GEMM_LN16, or the
+// standalone mfc_ln16_fwd): these kernels read h1 = LN_C(h0) and the per-pixel 1/sigma (rho0, only
+// needed by the tangent and by the reverse pass), so staging a tile is one FMA per element.
 // Data layout: NHWC maps [R, s, s, 16] in the storage dtype T (fp32 or bf16).
 // One workgroup = one 16x16 pixel tile (+1 halo) of one row r, 4 waves, each
 // wave owns 4 tile rows of 16 pixels = one MFMA M-tile.  Every per-pixel
@@ -187,8 +190,8 @@ __device__ inline Lds<T> carve(unsigned char* base, bool aux, bool ws, int wave)
 }
 
 // Halo staging, split so the global loads of tile t+1 fly while tile t computes:
-//   halo_load   : raw h0 (and tangent) of the (TH+2)x(TW+2) halo -> registers (thread-per-pixel)
-//   halo_commit : h2 = FiLM(LN(h0)) (and its tangent) -> LDS, zero outside the image
+//   halo_load   : h1 = LN(h0) (and raw tangent h0dot + rho0) of the (TH+2)x(TW+2) halo -> registers
+//   halo_commit : h2 = FiLM(h1) (and its tangent) -> LDS, zero outside the image
 __device__ inline void unfrag(const f32x4& f, float v[4]) { v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3]; }
 __device__ inline void unfrag(const s16x4& f, float v[4]) {
 #pragma unroll
@@ -197,10 +200,12 @@ __device__ inline void unfrag(const s16x4& f, float v[4]) {
 constexpr int HPT = (NHALO + NT - 1) / NT;  // halo pixels per thread (2)
 template <typename T, bool JVP> struct HaloRaw {
     typename Frag<T>::type v[HPT][4], vd[JVP ? HPT : 1][4];
+    float rho[JVP ? HPT : 1];
     unsigned ok;
 };
 template <typename T, bool JVP>
-__device__ inline void halo_load(HaloRaw<T, JVP>& h, const T* src, const T* srcd, int64_t r, int s, int y0, int x0) {
+__device__ inline void halo_load(HaloRaw<T, JVP>& h, const T* src, const T* srcd, const float* rho0, int64_t r,
+                                 int s, int y0, int x0) {
     typedef typename Frag<T>::type frag_t;
     h.ok = 0;
 #pragma unroll
@@ -216,6 +221,7 @@ __device__ inline void halo_load(HaloRaw<T, JVP>& h, const T* src, const T* srcd
                 h.v[k][i] = *reinterpret_cast<const frag_t*>(src + off + 4 * i);
                 if constexpr (JVP) h.vd[k][i] = *reinterpret_cast<const frag_t*>(srcd + off + 4 * i);
             }
+            if constexpr (JVP) h.rho[k] = rho0[(r * s + gy) * (int64_t)s + gx];
         }
     }
 }
@@ -227,21 +233,14 @@ __device__ inline void halo_commit(const Lds<T>& l, const HaloRaw<T, JVP>& h) {
         if (hp >= NHALO) continue;
         float h2[16], h2d[16];
         if (h.ok & (1u << k)) {
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) unfrag(h.v[k][i], v + 4 * i);
-            float sum = 0.f, sq = 0.f;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) { sum += v[c]; sq += v[c] * v[c]; }
-            const float mean = sum * (1.0f / 16.0f);
-            const float rho = rsqrtf(fmaxf(0.0f, sq * (1.0f / 16.0f) - mean * mean) + LN_EPS);
             float h1[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                h1[c] = (v[c] - mean) * rho;
-                h2[c] = (1.0f + l.fsc[c]) * h1[c] + l.fsc[16 + c];
-            }
+            for (int i = 0; i < 4; ++i) unfrag(h.v[k][i], h1 + 4 * i);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) h2[c] = (1.0f + l.fsc[c]) * h1[c] + l.fsc[16 + c];
             if constexpr (JVP) {
+                // tangent of the fused LayerNorm: h1dot = rho0 (h0dot_c - h1 mean(h1 h0dot_c))
+                const float rho = h.rho[k];
                 float vd[16];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) unfrag(h.vd[k][i], vd + 4 * i);
@@ -377,7 +376,7 @@ __device__ inline void chain_row(const Lds<T>& l, const FwdW<T>& w, int y, int q
 
 struct FwdArgs {
     Geo geo;
-    const void* h0; const void* h0d;
+    const void* h0; const void* h0d; const float* rho;
     const float* sc; const float* sh; const float* scd; const float* shd;
     Dev p;
     float* S1; float* S2;          // stats mode
@@ -438,7 +437,7 @@ cnx_fwd_kernel(FwdArgs a) {
     };
 
     HaloRaw<T, JVP> raw;
-    if (t0 < t1) { const TileCoord c = tile_coord(a.geo, t0); halo_load<T, JVP>(raw, h0, h0d, c.r, s, c.y0, c.x0); }
+    if (t0 < t1) { const TileCoord c = tile_coord(a.geo, t0); halo_load<T, JVP>(raw, h0, h0d, a.rho, c.r, s, c.y0, c.x0); }
     for (int64_t t = t0; t < t1; ++t) {
         const TileCoord tc = tile_coord(a.geo, t);
         const int64_t r = tc.r;
@@ -461,7 +460,7 @@ cnx_fwd_kernel(FwdArgs a) {
         }
         if (!(a.dbg & 2) || t == t0) halo_commit<T, JVP>(l, raw);
         __syncthreads();
-        if (t + 1 < t1 && !(a.dbg & 2)) { const TileCoord c = tile_coord(a.geo, t + 1); halo_load<T, JVP>(raw, h0, h0d, c.r, s, c.y0, c.x0); }
+        if (t + 1 < t1 && !(a.dbg & 2)) { const TileCoord c = tile_coord(a.geo, t + 1); halo_load<T, JVP>(raw, h0, h0d, a.rho, c.r, s, c.y0, c.x0); }
         const int gx = x0 + m;
 #pragma unroll 1
         for (int ri = 0; ri < ((a.dbg & 1) ? 0 : RPW); ++ri) {
@@ -525,7 +524,7 @@ cnx_fwd_kernel(FwdArgs a) {
 // ---------------------------------------------------------------------------
 struct BwdArgs {
     Geo geo;
-    const void* h0; const float* sc; const float* sh;
+    const void* h0; const float* rho; const float* sc; const float* sh;
     Dev p; DevG g;
     const float* q; const float* kG;
     const void* dout; const void* dc1_in;
@@ -606,7 +605,7 @@ cnx_bwd_kernel(BwdArgs a) {
     frag_t dnext[RPW];
     if (t0 < t1) {
         const TileCoord c = tile_coord(a.geo, t0);
-        halo_load<T, false>(raw, h0, nullptr, c.r, s, c.y0, c.x0);
+        halo_load<T, false>(raw, h0, nullptr, nullptr, c.r, s, c.y0, c.x0);
         load_dout(dnext, c);
     }
     for (int64_t t = t0; t < t1; ++t) {
@@ -635,7 +634,7 @@ cnx_bwd_kernel(BwdArgs a) {
         __syncthreads();
         if (t + 1 < t1) {
             const TileCoord c = tile_coord(a.geo, t + 1);
-            halo_load<T, false>(raw, h0, nullptr, c.r, s, c.y0, c.x0);
+            halo_load<T, false>(raw, h0, nullptr, nullptr, c.r, s, c.y0, c.x0);
             load_dout(dnext, c);
         }
 #pragma unroll 1
@@ -794,27 +793,30 @@ cnx_bwd_conv_kernel(BwdArgs a) {
     };
 
     // centre-pixel dout / h0 of this wave's rows, fetched one tile ahead
-    auto load_centre = [&](frag_t d[RPW], frag_t hh[RPW], const TileCoord& c) {
+    auto load_centre = [&](frag_t d[RPW], frag_t hh[RPW], float rr[RPW], const TileCoord& c) {
 #pragma unroll
         for (int ri = 0; ri < RPW; ++ri) {
             const int gy = c.y0 + wave * RPW + ri, gxx = c.x0 + m;
             if (gy < s && gxx < s) {
-                const int64_t goff = ((c.r * s + gy) * (int64_t)s + gxx) * 16 + 4 * q;
-                d[ri] = *reinterpret_cast<const frag_t*>(dout + goff);
-                hh[ri] = *reinterpret_cast<const frag_t*>(h0 + goff);
+                const int64_t pix = (c.r * s + gy) * (int64_t)s + gxx;
+                d[ri] = *reinterpret_cast<const frag_t*>(dout + pix * 16 + 4 * q);
+                hh[ri] = *reinterpret_cast<const frag_t*>(h0 + pix * 16 + 4 * q);
+                rr[ri] = a.rho[pix];
             } else {
                 frag_raw(d[ri], (T)0, (T)0, (T)0, (T)0);
                 frag_raw(hh[ri], (T)0, (T)0, (T)0, (T)0);
+                rr[ri] = 0.f;
             }
         }
     };
     HaloRaw<T, false> raw, rawd;
     frag_t dnext[RPW], hnext[RPW];
+    float rnext[RPW];
     if (t0 < t1) {
         const TileCoord c = tile_coord(a.geo, t0);
-        halo_load<T, false>(raw, h0, nullptr, c.r, s, c.y0, c.x0);
-        halo_load<T, false>(rawd, dc1, nullptr, c.r, s, c.y0, c.x0);
-        load_centre(dnext, hnext, c);
+        halo_load<T, false>(raw, h0, nullptr, nullptr, c.r, s, c.y0, c.x0);
+        halo_load<T, false>(rawd, dc1, nullptr, nullptr, c.r, s, c.y0, c.x0);
+        load_centre(dnext, hnext, rnext, c);
     }
     for (int64_t t = t0; t < t1; ++t) {
         const TileCoord tc = tile_coord(a.geo, t);
@@ -823,8 +825,9 @@ cnx_bwd_conv_kernel(BwdArgs a) {
         const int gx = x0 + m;
         __syncthreads();
         frag_t dcur[RPW], hcur[RPW];
+        float rcur4[RPW];
 #pragma unroll
-        for (int ri = 0; ri < RPW; ++ri) { dcur[ri] = dnext[ri]; hcur[ri] = hnext[ri]; }
+        for (int ri = 0; ri < RPW; ++ri) { dcur[ri] = dnext[ri]; hcur[ri] = hnext[ri]; rcur4[ri] = rnext[ri]; }
         if (r != rcur) {
             if (rcur >= 0) flush_row(rcur);
             rcur = r;
@@ -838,19 +841,20 @@ cnx_bwd_conv_kernel(BwdArgs a) {
         __syncthreads();
         if (t + 1 < t1) {
             const TileCoord c = tile_coord(a.geo, t + 1);
-            halo_load<T, false>(raw, h0, nullptr, c.r, s, c.y0, c.x0);
-            halo_load<T, false>(rawd, dc1, nullptr, c.r, s, c.y0, c.x0);
-            load_centre(dnext, hnext, c);
+            halo_load<T, false>(raw, h0, nullptr, nullptr, c.r, s, c.y0, c.x0);
+            halo_load<T, false>(rawd, dc1, nullptr, nullptr, c.r, s, c.y0, c.x0);
+            load_centre(dnext, hnext, rnext, c);
         }
 #pragma unroll 1
         for (int ri = 0; ri < RPW; ++ri) {
             const int y = wave * RPW + ri;
             const int gy = y0 + y;
-            float dov[4], hv[4];
+            float dov[4], h1[4];
             unfrag(dcur[0], dov);
-            unfrag(hcur[0], hv);
+            unfrag(hcur[0], h1);
+            const float rho = rcur4[0];
 #pragma unroll
-            for (int k = 0; k + 1 < RPW; ++k) { dcur[k] = dcur[k + 1]; hcur[k] = hcur[k + 1]; }
+            for (int k = 0; k + 1 < RPW; ++k) { dcur[k] = dcur[k + 1]; hcur[k] = hcur[k + 1]; rcur4[k] = rcur4[k + 1]; }
             // dh2 = conv^T(dc1): h2[p] feeds c1[p - (i-1, j-1)] through K[i][j]
             f32x4 dh = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -874,10 +878,9 @@ cnx_bwd_conv_kernel(BwdArgs a) {
             }
             if (gy < s && gx < s) {
                 const int64_t goff = ((r * s + gy) * (int64_t)s + gx) * 16 + 4 * q;
-                float d2[4], h1[4], mean, rho, dh1[4], dx[4];
+                float d2[4], dh1[4], dx[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) d2[i] = dh[i] + dov[i];  // residual branch o = ... + h2
-                ln_fwd_a(hv, h1, mean, rho);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     dscp[i] += d2[i] * h1[i];
@@ -894,6 +897,25 @@ cnx_bwd_conv_kernel(BwdArgs a) {
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) atomicAdd(a.g.conv_w + (t * 16 + 4 * q + e) * 16 + m, aWc[t][e]);
+}
+
+// standalone first LayerNorm (what mfc_gemm's MFC_GEMM_LN16 epilogue fuses): y = LN_16(x), rstd per pixel
+template <typename T>
+__global__ void __launch_bounds__(256) ln16_kernel(int64_t npix, const T* x, T* y, float* rstd) {
+    for (int64_t p = blockIdx.x * 256LL + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+        float v[16];
+        ld16<T>(x + p * 16, v);
+        float sum = 0.f, sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { sum += v[c]; sq += v[c] * v[c]; }
+        const float mean = sum * (1.0f / 16.0f);
+        const float rho = rsqrtf(fmaxf(0.0f, sq * (1.0f / 16.0f) - mean * mean) + LN_EPS);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = (v[c] - mean) * rho;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st4(y + p * 16 + 4 * i, v + 4 * i);
+        if (rstd) rstd[p] = rho;
+    }
 }
 
 __global__ void grn_finalize_kernel(int64_t R, const float* S1, const float* S2, float* G, float* qo, float* qd) {
@@ -963,7 +985,7 @@ int fwd_launch(bool jvp, int mode, const FwdArgs& a, int64_t grid, hipStream_t s
     return launch_k(cnx_fwd_kernel<T, false, 1>, grid, lds, st, a);
 }
 
-int fwd_common(int dtype, int mode, int64_t R, int s, const void* h0, const void* h0dot,
+int fwd_common(int dtype, int mode, int64_t R, int s, const void* h0, const float* rho0, const void* h0dot,
                const float* scale, const float* shift, const float* scaledot, const float* shiftdot,
                const mfc_cnx_params* p, float* S1, float* S2, const float* q, const float* qdot,
                void* o, void* odot, void* stream) {
@@ -971,13 +993,13 @@ int fwd_common(int dtype, int mode, int64_t R, int s, const void* h0, const void
     if (R <= 0 || s <= 0) return MFC_EINVAL;
     if (dtype != MFC_F32 && dtype != MFC_BF16) return MFC_EINVAL;
     const bool jvp = h0dot != nullptr;
-    if (jvp && (!scaledot || !shiftdot)) return MFC_EFAULT;
+    if (jvp && (!scaledot || !shiftdot || !rho0)) return MFC_EFAULT;
     if (mode == 0 && (!S1 || (jvp && !S2))) return MFC_EFAULT;
     if (mode == 1 && (!q || !o || (jvp && (!qdot || !odot)))) return MFC_EFAULT;
     FwdArgs a;
     int64_t grid;
     a.geo = make_geo(R, s, MAX_BLOCKS, grid);
-    a.h0 = h0; a.h0d = h0dot; a.sc = scale; a.sh = shift; a.scd = scaledot; a.shd = shiftdot;
+    a.h0 = h0; a.h0d = h0dot; a.rho = rho0; a.sc = scale; a.sh = shift; a.scd = scaledot; a.shd = shiftdot;
     a.p = to_dev(p); a.S1 = S1; a.S2 = S2; a.q = q; a.qd = qdot; a.o = o; a.od = odot;
     static const int dbg = getenv("MFC_CNX_DBG") ? atoi(getenv("MFC_CNX_DBG")) : 0;
     a.dbg = dbg;
@@ -987,19 +1009,19 @@ int fwd_common(int dtype, int mode, int64_t R, int s, const void* h0, const void
 
 }  // namespace
 
-extern "C" int mfc_cnx_stats(int dtype, int64_t R, int s, const void* h0, const void* h0dot,
+extern "C" int mfc_cnx_stats(int dtype, int64_t R, int s, const void* h1, const float* rho0, const void* h0dot,
                              const float* scale, const float* shift, const float* scaledot,
                              const float* shiftdot, const mfc_cnx_params* p, float* S1, float* S2,
                              void* stream) {
-    return fwd_common(dtype, 0, R, s, h0, h0dot, scale, shift, scaledot, shiftdot, p, S1, S2, nullptr, nullptr,
+    return fwd_common(dtype, 0, R, s, h1, rho0, h0dot, scale, shift, scaledot, shiftdot, p, S1, S2, nullptr, nullptr,
                       nullptr, nullptr, stream);
 }
 
-extern "C" int mfc_cnx_apply(int dtype, int64_t R, int s, const void* h0, const void* h0dot,
+extern "C" int mfc_cnx_apply(int dtype, int64_t R, int s, const void* h1, const float* rho0, const void* h0dot,
                              const float* scale, const float* shift, const float* scaledot,
                              const float* shiftdot, const mfc_cnx_params* p, const float* q, const float* qdot,
                              void* o, void* odot, void* stream) {
-    return fwd_common(dtype, 1, R, s, h0, h0dot, scale, shift, scaledot, shiftdot, p, nullptr, nullptr, q, qdot,
+    return fwd_common(dtype, 1, R, s, h1, rho0, h0dot, scale, shift, scaledot, shiftdot, p, nullptr, nullptr, q, qdot,
                       o, odot, stream);
 }
 
@@ -1054,10 +1076,11 @@ extern "C" int mfc_cnx_bwd_main(int dtype, int64_t R, int s, const void* h0, con
     return launch_k(cnx_bwd_kernel<u16, 1>, grid, lds_bytes<u16>(false, true), st, a);
 }
 
-extern "C" int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, const float* scale,
-                                const float* shift, const mfc_cnx_params* p, const void* dc1, const void* dout,
-                                void* dh0, const mfc_cnx_grads* g, float* dscale, float* dshift, void* stream) {
-    if (!h0 || !scale || !shift || !params_ok(p) || !dc1 || !dout || !dh0 || !g || !g->conv_w || !dscale ||
+extern "C" int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, const float* rho0,
+                                const float* scale, const float* shift, const mfc_cnx_params* p, const void* dc1,
+                                const void* dout, void* dh0, const mfc_cnx_grads* g, float* dscale, float* dshift,
+                                void* stream) {
+    if (!h0 || !rho0 || !scale || !shift || !params_ok(p) || !dc1 || !dout || !dh0 || !g || !g->conv_w || !dscale ||
         !dshift)
         return MFC_EFAULT;
     if (R <= 0 || s <= 0 || (dtype != MFC_F32 && dtype != MFC_BF16)) return MFC_EINVAL;
@@ -1065,8 +1088,23 @@ extern "C" int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, con
     int64_t grid;
     a.geo = make_geo(R, s, MAX_BLOCKS, grid);
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(g);
-    a.dc1_in = dc1; a.dout = dout; a.dh0 = dh0; a.dsc = dscale; a.dsh = dshift;
+    a.rho = rho0; a.dc1_in = dc1; a.dout = dout; a.dh0 = dh0; a.dsc = dscale; a.dsh = dshift;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MFC_F32) return launch_k(cnx_bwd_conv_kernel<float>, grid, lds_bytes<float>(true, false), st, a);
     return launch_k(cnx_bwd_conv_kernel<u16>, grid, lds_bytes<u16>(true, false), st, a);
+}
+
+extern "C" int mfc_ln16_fwd(int dtype, int64_t n_pixels, const void* x, void* y, float* rstd, void* stream) {
+    if (!x || !y) return MFC_EFAULT;
+    if (n_pixels <= 0 || (dtype != MFC_F32 && dtype != MFC_BF16)) return MFC_EINVAL;
+    int64_t grid = ceil_div64(n_pixels, 256);
+    if (grid > 16384) grid = 16384;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_F32)
+        hipLaunchKernelGGL(ln16_kernel<float>, dim3((unsigned)grid), dim3(256), 0, st, n_pixels, (const float*)x,
+                           (float*)y, rstd);
+    else
+        hipLaunchKernelGGL(ln16_kernel<u16>, dim3((unsigned)grid), dim3(256), 0, st, n_pixels, (const u16*)x, (u16*)y,
+                           rstd);
+    return mfc_launch_status();
 }

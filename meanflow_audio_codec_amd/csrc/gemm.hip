@@ -39,6 +39,7 @@ struct GemmArgs {
     int vecA, vecB;  // 16-byte vector loads legal
     int vecC;        // 16-byte row-contiguous C (and R) accesses legal
     int m_fast;      // blockIdx.x walks M tiles (else N tiles)
+    float* ln_rstd;  // MFC_GEMM_LN16: per-(row, 16-column group) 1/sigma, or null
 };
 
 template <typename T> struct Vec;   // 16-byte global vector
@@ -230,6 +231,17 @@ gemm_kernel(GemmArgs g) {
                 const bool hb = g.bias && row < g.bias_rows;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) v[k] = (v[k] + (hb ? g.bias[col0 + k] : 0.f)) * g.alpha;
+                if (g.ln_rstd && row < g.bias_rows) {
+                    // fused first LayerNorm of the ConvNeXt block: this lane holds one pixel's 16 channels
+                    float sum = 0.f, sq = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { sum += v[k]; sq += v[k] * v[k]; }
+                    const float mean = sum * (1.0f / 16.0f);
+                    const float rho = rsqrtf(fmaxf(0.0f, sq * (1.0f / 16.0f) - mean * mean) + 1e-6f);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] = (v[k] - mean) * rho;
+                    g.ln_rstd[row * (g.N >> 4) + (col0 >> 4)] = rho;
+                }
                 T* cp = C + row * g.ldc + col0;
                 if constexpr (sizeof(T) == 4) {
                     if (R) {
@@ -366,7 +378,7 @@ extern "C" int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
                         void* C, int64_t ldc,
                         const float* bias, int64_t bias_rows, int64_t act_rows,
                         float alpha, const void* R, int64_t ldr, float beta_res,
-                        int splitk, float* ws, void* stream) {
+                        int splitk, float* ws, float* ln_rstd, void* stream) {
     if (!A || !B || !C) return MFC_EFAULT;
     if (M <= 0 || N <= 0 || K <= 0) return MFC_EINVAL;
     if (dtype != MFC_F32 && dtype != MFC_BF16) return MFC_EINVAL;
@@ -398,6 +410,12 @@ extern "C" int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
     g.vecB = (((ldb * es) % 16) == 0) && (((uintptr_t)B % 16) == 0);
     g.vecC = (N % 16 == 0) && ((ldc * es) % 16 == 0) && (((uintptr_t)C % 16) == 0) &&
              (!R || (((ldr * es) % 16 == 0) && (((uintptr_t)R % 16) == 0)));
+    g.ln_rstd = nullptr;
+    if (flags & MFC_GEMM_LN16) {
+        if (!ln_rstd) return MFC_EFAULT;
+        if (!g.vecC || use_ws) return MFC_ENOSYS;
+        g.ln_rstd = ln_rstd;
+    }
     if (use_ws) {
         if (hipMemsetAsync(ws, 0, (size_t)M * N * sizeof(float), st) != hipSuccess) return MFC_EHIP;
     }

@@ -30,7 +30,7 @@ BOTTLENECK = 128  # models/conv_flow.py:142,153
 
 class ConvCtx:
     """Saved primal activations of one forward pass (consumed by ``backward``)."""
-    __slots__ = ("R", "x_in", "a1", "g1", "a2", "g2", "H0", "O", "G", "q", "sc", "sh", "cond", "lat", "enc")
+    __slots__ = ("R", "x_in", "a1", "g1", "a2", "g2", "H0", "rho", "O", "G", "q", "sc", "sh", "cond", "lat", "enc")
 
     def __init__(self):
         for k in self.__slots__:
@@ -182,18 +182,24 @@ class ConditionalConvFlow:
             ctx.cond = cond
             # block i primal rows live at [i*R, (i+1)*R); its tangent rows spill into the head of block
             # i+1's region and are dead before that region is written.
-            ctx.H0 = self._buf(("H0save", R, n_tan), (K * R + n_tan, S), T, dev)
+            ctx.H0 = self._buf(("H0save", R, n_tan), (K * R + n_tan, S), T, dev)    # holds h1 = LN(h0) (primal rows)
             ctx.O = self._buf(("Osave", R, n_tan), (K * R + n_tan, S), T, dev)
+            ctx.rho = self._buf(("rhosave", R), (K, R, S // 16), torch.float32, dev)
         else:
             H0s = self._buf(("H0", Rt), (Rt, S), T, dev)
             Os = self._buf(("O", Rt), (Rt, S), T, dev)
+            rhos = self._buf(("rho", R), (R, S // 16), torch.float32, dev)
         for i in range(K):
             b = f"blocks_{i}"
             a1 = dense(X, w[f"{b}/input_proj1/kernel"], w[f"{b}/input_proj1/bias"], bias_rows=R)
             g1 = ops.gelu_fwd(a1, act_rows=R)
             H0 = ctx.H0[i * R:i * R + Rt] if save else H0s
             O = ctx.O[i * R:i * R + Rt] if save else Os
-            dense(g1, w[f"{b}/input_proj2/kernel"], w[f"{b}/input_proj2/bias"], bias_rows=R, out=H0)
+            rho = ctx.rho[i] if save else rhos
+            # h0 = g1 W2 + b2 with the block's first LayerNorm fused into the epilogue: the primal rows of H0
+            # hold h1 = LN(h0), rho its per-pixel 1/sigma; tangent rows stay raw (h0dot)
+            ops.gemm(g1, w[f"{b}/input_proj2/kernel"], bias=w[f"{b}/input_proj2/bias"], bias_rows=R, out=H0,
+                     ln_rstd=rho)
             cp = dense(cstack, w[f"{b}/conditioning_layer/kernel"], w[f"{b}/conditioning_layer/bias"], bias_rows=R)
             sc, sh = cp[:R, :16].contiguous(), cp[:R, 16:].contiguous()
             cw = self._cnx_w(w, i)
@@ -201,7 +207,7 @@ class ConditionalConvFlow:
             if n_tan:
                 scd, shd = cp[R:, :16].contiguous(), cp[R:, 16:].contiguous()
                 _, _, G, q = ops.cnx_forward(H0[:n_tan], sc[:n_tan], sh[:n_tan], cw, s, h0dot=H0[R:],
-                                             scaledot=scd, shiftdot=shd, out=O[:n_tan], outdot=O[R:])
+                                             scaledot=scd, shiftdot=shd, out=O[:n_tan], outdot=O[R:], rho0=rho)
                 Gs.append(G); qs.append(q)
             if R > n_tan:
                 _, _, G, q = ops.cnx_forward(H0[n_tan:R], sc[n_tan:], sh[n_tan:], cw, s, out=O[n_tan:R])
@@ -256,7 +262,7 @@ class ConditionalConvFlow:
             for t_ in cg.values():
                 t_.zero_()
             _, dsc, dsh = ops.cnx_backward(H0, ctx.sc[i], ctx.sh[i], self._cnx_w(w, i), s, ctx.G[i], ctx.q[i], dO, cg,
-                                           dh0=dH0, scratch=dC1)
+                                           dh0=dH0, scratch=dC1, rho0=ctx.rho[i])
             dcp = torch.cat([dsc, dsh], 1).contiguous()
             dense_dw(ctx.cond, dcp, out=grads[f"{b}/conditioning_layer/kernel"])
             ops.colsum(dcp, out=grads[f"{b}/conditioning_layer/bias"])

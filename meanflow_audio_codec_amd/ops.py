@@ -4,12 +4,12 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import GEMM_ACCUM, GEMM_GELU, GEMM_TRANS_A, GEMM_TRANS_B  # noqa: F401
+from ._lib import GEMM_ACCUM, GEMM_GELU, GEMM_LN16, GEMM_TRANS_A, GEMM_TRANS_B  # noqa: F401
 
 
 def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a=False, trans_b=False, bias=None, bias_rows=None,
          gelu=False, act_rows=None, alpha=1.0, residual=None, beta=1.0, out=None, accumulate=False,
-         splitk=1, ws=None) -> torch.Tensor:
+         splitk=1, ws=None, ln_rstd=None) -> torch.Tensor:
     """C = alpha*(op(A) op(B) + bias) + beta*residual through ``mfc_gemm``.
 
     A: [M,K] (or [K,M] if trans_a), B: [K,N] (or [N,K] if trans_b); 2-D, last
@@ -25,7 +25,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a=False, trans_b=False, bias
         out = torch.empty((M, N), dtype=A.dtype, device=A.device)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == A.dtype
     flags = (GEMM_TRANS_A if trans_a else 0) | (GEMM_TRANS_B if trans_b else 0) \
-        | (GEMM_ACCUM if accumulate else 0) | (GEMM_GELU if gelu else 0)
+        | (GEMM_ACCUM if accumulate else 0) | (GEMM_GELU if gelu else 0) | (GEMM_LN16 if ln_rstd is not None else 0)
+    if ln_rstd is not None:
+        assert ln_rstd.dtype == torch.float32 and ln_rstd.is_contiguous() and N % 16 == 0
+        assert ln_rstd.numel() >= (M if bias_rows is None else bias_rows) * (N // 16)
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N
     if bias_rows is None:
@@ -40,7 +43,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a=False, trans_b=False, bias
         _lib.dtype_code(A.dtype), flags, M, N, K, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0),
         out.data_ptr(), out.stride(0), _lib.ptr(bias), bias_rows, act_rows, float(alpha),
         _lib.ptr(residual), residual.stride(0) if residual is not None else 0, float(beta),
-        int(splitk), _lib.ptr(ws), _lib.stream_ptr())
+        int(splitk), _lib.ptr(ws), _lib.ptr(ln_rstd), _lib.stream_ptr())
     _lib.check(rc, "mfc_gemm")
     return out
 
@@ -79,10 +82,22 @@ def _film(x, R):
     return x
 
 
+def ln16(x, want_rstd=True):
+    """Standalone first LayerNorm: (h1, rho0) from a raw [R, s, s, 16] map (mfc_ln16_fwd)."""
+    assert x.is_contiguous() and x.numel() % 16 == 0
+    npix = x.numel() // 16
+    y = torch.empty_like(x)
+    rstd = torch.empty(npix, dtype=torch.float32, device=x.device) if want_rstd else None
+    _lib.check(_lib.lib().mfc_ln16_fwd(_lib.dtype_code(x.dtype), npix, x.data_ptr(), y.data_ptr(), _lib.ptr(rstd),
+                                       _lib.stream_ptr()), "mfc_ln16_fwd")
+    return y, rstd
+
+
 def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, shiftdot=None, out=None,
-                outdot=None):
-    """o = ConvNeXtBlock(FiLM(LN(h0))) on [R, s, s, 16]; returns (o, odot, G, q).
-    Runs mfc_cnx_stats -> mfc_grn_finalize -> mfc_cnx_apply."""
+                outdot=None, rho0=None):
+    """o = ConvNeXtBlock(FiLM(h1)) on [R, s, s, 16] where ``h0`` holds h1 = LN(h0) (see ln16 / the
+    MFC_GEMM_LN16 epilogue), ``rho0`` its per-pixel 1/sigma and ``h0dot`` the RAW tangent of h0;
+    returns (o, odot, G, q).  Runs mfc_cnx_stats -> mfc_grn_finalize -> mfc_cnx_apply."""
     _lib.require_cuda(h0)
     R = h0.shape[0]
     dt = _lib.dtype_code(h0.dtype)
@@ -93,6 +108,7 @@ def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, sh
     if jvp:
         assert h0dot.is_contiguous() and h0dot.shape == h0.shape and h0dot.dtype == h0.dtype
         _film(scaledot, R), _film(shiftdot, R)
+        assert rho0 is not None and rho0.dtype == torch.float32 and rho0.is_contiguous() and rho0.numel() >= R * s * s
     L = _lib.lib()
     st = _lib.stream_ptr()
     ps = _cnx_struct(w)
@@ -101,22 +117,24 @@ def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, sh
     G = torch.empty((R, 32), dtype=torch.float32, device=dev)
     q = torch.empty_like(G)
     qd = torch.empty_like(G) if jvp else None
-    _lib.check(L.mfc_cnx_stats(dt, R, s, h0.data_ptr(), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
+    _lib.check(L.mfc_cnx_stats(dt, R, s, h0.data_ptr(), _lib.ptr(rho0), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
                                _lib.ptr(scaledot), _lib.ptr(shiftdot), ctypes.byref(ps), S[0].data_ptr(),
                                S[1].data_ptr() if jvp else None, st), "mfc_cnx_stats")
     _lib.check(L.mfc_grn_finalize(R, S[0].data_ptr(), S[1].data_ptr() if jvp else None, G.data_ptr(),
                                   q.data_ptr(), _lib.ptr(qd), st), "mfc_grn_finalize")
     o = out if out is not None else torch.empty_like(h0)
     od = (outdot if outdot is not None else torch.empty_like(h0)) if jvp else None
-    _lib.check(L.mfc_cnx_apply(dt, R, s, h0.data_ptr(), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
+    _lib.check(L.mfc_cnx_apply(dt, R, s, h0.data_ptr(), _lib.ptr(rho0), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
                                _lib.ptr(scaledot), _lib.ptr(shiftdot), ctypes.byref(ps), q.data_ptr(),
                                _lib.ptr(qd), o.data_ptr(), _lib.ptr(od), st), "mfc_cnx_apply")
     return o, od, G, q
 
 
-def cnx_backward(h0, scale, shift, w: dict, s: int, G, q, dout, grads: dict, dh0=None, scratch=None):
-    """Backward of cnx_forward's primal: returns (dh0, dscale, dshift); accumulates (+=) the
-    small-parameter gradients into the fp32 tensors of ``grads`` (same keys as ``w``)."""
+def cnx_backward(h0, scale, shift, w: dict, s: int, G, q, dout, grads: dict, dh0=None, scratch=None, rho0=None):
+    """Backward of cnx_forward's primal (``h0`` = h1 = LN(h0), ``rho0`` its 1/sigma): returns
+    (dh0, dscale, dshift) with dh0 the gradient w.r.t. the RAW h0 (LayerNorm backward included);
+    accumulates (+=) the small-parameter gradients into the fp32 tensors of ``grads``."""
+    assert rho0 is not None and rho0.dtype == torch.float32 and rho0.is_contiguous()
     _lib.require_cuda(h0, dout)
     R = h0.shape[0]
     dt = _lib.dtype_code(h0.dtype)
@@ -143,7 +161,7 @@ def cnx_backward(h0, scale, shift, w: dict, s: int, G, q, dout, grads: dict, dh0
         dh0 = torch.empty_like(h0)
     dsc = torch.zeros((R, 16), dtype=torch.float32, device=dev)
     dsh = torch.zeros_like(dsc)
-    _lib.check(L.mfc_cnx_bwd_conv(dt, R, s, h0.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctypes.byref(ps),
+    _lib.check(L.mfc_cnx_bwd_conv(dt, R, s, h0.data_ptr(), rho0.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctypes.byref(ps),
                                   dc1.data_ptr(), dout.data_ptr(), dh0.data_ptr(), ctypes.byref(gs),
                                   dsc.data_ptr(), dsh.data_ptr(), st), "mfc_cnx_bwd_conv")
     return dh0, dsc, dsh

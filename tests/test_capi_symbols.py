@@ -31,4 +31,4 @@ def test_argument_checks_fail_loudly_without_launching():
     l = _lib.lib()
     assert l.mfc_mdct_fwd(None, 1, 10, 10, 8, 4, None, None) == -14
     assert l.mfc_gemm(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, ctypes.c_float(1.0), None, 0,
-                      ctypes.c_float(0.0), 1, None, None) == -14
+                      ctypes.c_float(0.0), 1, None, None, None) == -14

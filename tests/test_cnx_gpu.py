@@ -58,12 +58,13 @@ def test_forward_and_jvp(dtype, tol, R, s):
     o_ref, od_ref = torch.func.jvp(lambda a, b, c: _oracle(pq, a, b, c), (h0q, sc, sh), (h0dq, scd, shd))
     w = _weights(p, dtype)
     f32 = lambda t: t.float().contiguous().cuda()
-    o, od, G, q = ops.cnx_forward(h0.to(dtype).cuda(), f32(sc), f32(sh), w, s,
-                                  h0dot=h0d.to(dtype).cuda(), scaledot=f32(scd), shiftdot=f32(shd))
+    h1, rho = ops.ln16(h0.to(dtype).cuda())          # the first LayerNorm is a separate (GEMM-fused) step
+    o, od, G, q = ops.cnx_forward(h1, f32(sc), f32(sh), w, s, h0dot=h0d.to(dtype).cuda(), scaledot=f32(scd),
+                                  shiftdot=f32(shd), rho0=rho)
     assert _rel(o, o_ref) < tol, ("primal", _rel(o, o_ref))
     assert _rel(od, od_ref) < tol, ("tangent", _rel(od, od_ref))
     # primal-only entry gives the same primal
-    o2, od2, _, _ = ops.cnx_forward(h0.to(dtype).cuda(), f32(sc), f32(sh), w, s)
+    o2, od2, _, _ = ops.cnx_forward(h1, f32(sc), f32(sh), w, s)
     assert od2 is None
     assert _rel(o2, o_ref) < tol
 
@@ -90,10 +91,10 @@ def test_backward(dtype, tol, R, s):
 
     w = _weights(p, dtype)
     f32 = lambda t: t.float().contiguous().cuda()
-    h0g = h0.to(dtype).cuda()
+    h0g, rho = ops.ln16(h0.to(dtype).cuda())
     o, _, G, q = ops.cnx_forward(h0g, f32(sc), f32(sh), w, s)
     gacc = {k: torch.zeros(v.shape, dtype=torch.float32, device="cuda") for k, v in w.items()}
-    dh0, dsc, dsh = ops.cnx_backward(h0g, f32(sc), f32(sh), w, s, G, q, dout.to(dtype).cuda(), gacc)
+    dh0, dsc, dsh = ops.cnx_backward(h0g, f32(sc), f32(sh), w, s, G, q, dout.to(dtype).cuda(), gacc, rho0=rho)
     checks = {
         "h0": (dh0, gref["h0"]), "sc": (dsc, gref["sc"]), "sh": (dsh, gref["sh"]),
         "conv_w": (gacc["conv_w"], gref["Conv_0/kernel"]), "conv_b": (gacc["conv_b"], gref["Conv_0/bias"]),

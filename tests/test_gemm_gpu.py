@@ -83,3 +83,24 @@ def test_gemm_rejects_cpu_tensors():
     from meanflow_audio_codec_amd._lib import MfcError
     with pytest.raises(MfcError):
         ops.gemm(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_gemm_ln16_epilogue(dtype, tol):
+    """MFC_GEMM_LN16: primal rows get LayerNorm over every 16-column group (+ 1/sigma out), tangent rows stay raw."""
+    from meanflow_audio_codec_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    R, nt, K, N = 20, 7, 128, 16 * 37
+    X = torch.randn(R + nt, K, generator=g, device="cuda").to(dtype)
+    W = torch.randn(K, N, generator=g, device="cuda").to(dtype)
+    b = torch.randn(N, generator=g, device="cuda")
+    rho = torch.zeros(R, N // 16, device="cuda")
+    C = ops.gemm(X, W, bias=b, bias_rows=R, ln_rstd=rho)
+    pre = X.double() @ W.double()
+    pre[:R] += b.double()
+    grp = pre[:R].reshape(R, N // 16, 16)
+    mu, var = grp.mean(-1, keepdim=True), grp.var(-1, unbiased=False, keepdim=True)
+    ref = torch.cat([((grp - mu) * torch.rsqrt(var + 1e-6)).reshape(R, N), pre[R:]], 0)
+    assert (C.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    assert ((rho.double() - torch.rsqrt(var + 1e-6).reshape(R, -1)).abs().max() /
+            torch.rsqrt(var + 1e-6).max()).item() < (1e-4 if dtype == torch.float32 else 2e-2)
