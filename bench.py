@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--decode-batch", type=int, default=None)
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (no roofline)")
     ap.add_argument("--no-overlap", action="store_true", help="reference order: loss -> all-reduce -> AdamW")
+    ap.add_argument("--overlap", action="store_true",
+                    help="per-block exchange + AdamW on a side stream during the reverse pass (default for --gpus > 1; "
+                         "on one GPU it gains ~1%% and blurs the per-kernel timings, so it is off)")
     return ap.parse_args()
 
 
@@ -289,10 +292,12 @@ def main():
     clips = 0.1 * torch.randn(B, wl["T"], generator=g, device=device)
     key = PRNGKey(42)
 
+    use_overlap = (world > 1 or args.overlap) and not args.no_overlap
+
     def one_step(state, key):
         tokens = tok.tokenize(clips)
         return train_step(state, key, tokens.reshape(B, -1), strat, reducer=reducer, row0=rank * B,
-                          global_batch=world * B, overlap=not args.no_overlap)
+                          global_batch=world * B, overlap=use_overlap)
 
     def barrier():
         if world > 1:
@@ -332,7 +337,7 @@ def main():
                                f"(N={wl['window']}, hop={wl['hop']} -> D={D}), cond={wl['cond']}, latent={wl['latent']}, "
                                f"blocks={wl['blocks']}, {n_params / 1e9:.2f} B params, AdamW fp32 master",
                    "per_gpu_batch": B, "global_batch": world * B, "parallelism": f"dp{world}"},
-        "loss": loss_vals,
+        "loss": loss_vals, "overlap_exchange_and_adamw": bool(use_overlap),
     }
 
     if rank == 0:

@@ -46,81 +46,65 @@ template <typename T> struct Vec;   // 16-byte global vector
 template <> struct Vec<float> { typedef f32x4 type; static constexpr int W = 4; };
 template <> struct Vec<u16> { typedef s16x8 type; static constexpr int W = 8; };
 
-// load W consecutive elements (valid = number in range), zero fill
+// load one 16-byte vector of W consecutive elements (valid = number in range), zero fill
 template <typename T>
-__device__ inline void loadv(const T* p, int64_t valid, bool vec, T* out) {
+__device__ inline typename Vec<T>::type loadv(const T* p, int64_t valid, bool vec) {
     constexpr int W = Vec<T>::W;
+    typename Vec<T>::type v;
     if (vec && valid >= W) {
-        const typename Vec<T>::type v = *reinterpret_cast<const typename Vec<T>::type*>(p);
-#pragma unroll
-        for (int i = 0; i < W; ++i) out[i] = (T)v[i];
+        v = *reinterpret_cast<const typename Vec<T>::type*>(p);
     } else {
 #pragma unroll
-        for (int i = 0; i < W; ++i) out[i] = (i < valid) ? p[i] : (T)0;
+        for (int i = 0; i < W; ++i) v[i] = (i < valid) ? p[i] : (T)0;
     }
+    return v;
 }
 
-// Stage one operand tile (128 rows x BK) into registers / from registers into LDS.
-//  KC = true : source is K-contiguous   src[row*ld + k]
-//  KC = false: source is row-contiguous src[k*ld + row]
+// Stage one operand tile (128 rows x BK) into registers / from registers into LDS.  The staging
+// registers stay packed 16-byte vectors (bf16: 8 elements in 4 VGPRs).
+//  KC = true : source is K-contiguous   src[row*ld + k]   -> LDS tile [128][LDK]
+//  KC = false: source is row-contiguous src[k*ld + row]   -> LDS tile [BK][LDR] (no transpose on the way in)
 template <typename T, int BK, bool KC> struct Stage {
+    typedef typename Vec<T>::type vec_t;
     static constexpr int W = Vec<T>::W;
     static constexpr int LDK = ldk_of(BK, sizeof(T));
-    // KC geometry
-    static constexpr int TPR = BK / W, RPP = GT / TPR, NP = 128 / RPP;
-    // !KC geometry: the tile stays [k][row] in LDS (no transpose on the way in): 128/W threads per
-    // k-row, 2W k-rows per pass
     static constexpr int LDR = ldr_of(sizeof(T));
-    static constexpr int TPK = 128 / W, KPP = GT / TPK, NPT = BK / KPP;
-    static constexpr int NREG = KC ? NP * W : NPT * W;
+    static constexpr int TPR = BK / W, RPP = GT / TPR, NP = 128 / RPP;       // KC geometry
+    static constexpr int TPK = 128 / W, KPP = GT / TPK, NPT = BK / KPP;     // !KC geometry
+    static constexpr int NV = KC ? NP : NPT;                                // vectors per thread
 
     __device__ static inline void load(const T* src, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
-                                       int64_t kend, bool vec, T* regs) {
+                                       int64_t kend, bool vec, vec_t* regs) {
         const int t = threadIdx.x;
+        vec_t z;
+#pragma unroll
+        for (int i = 0; i < W; ++i) z[i] = (T)0;
         if constexpr (KC) {
             const int kk = (t % TPR) * W, rr = t / TPR;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int64_t row = row0 + rr + RPP * p, k = k0 + kk;
-                if (row < nrows && k < kend) loadv<T>(src + row * ld + k, kend - k, vec, regs + W * p);
-                else {
-#pragma unroll
-                    for (int i = 0; i < W; ++i) regs[W * p + i] = (T)0;
-                }
+                regs[p] = (row < nrows && k < kend) ? loadv<T>(src + row * ld + k, kend - k, vec) : z;
             }
         } else {
             const int rr = (t % TPK) * W, kk = t / TPK;
 #pragma unroll
             for (int p = 0; p < NPT; ++p) {
                 const int64_t k = k0 + kk + KPP * p, row = row0 + rr;
-                if (k < kend && row < nrows) loadv<T>(src + k * ld + row, nrows - row, vec, regs + W * p);
-                else {
-#pragma unroll
-                    for (int i = 0; i < W; ++i) regs[W * p + i] = (T)0;
-                }
+                regs[p] = (k < kend && row < nrows) ? loadv<T>(src + k * ld + row, nrows - row, vec) : z;
             }
         }
     }
-    __device__ static inline void store(T* lds, const T* regs) {
+    __device__ static inline void store(T* lds, const vec_t* regs) {
         const int t = threadIdx.x;
         if constexpr (KC) {
             const int kk = (t % TPR) * W, rr = t / TPR;
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                typename Vec<T>::type v;
-#pragma unroll
-                for (int i = 0; i < W; ++i) v[i] = regs[W * p + i];
-                *reinterpret_cast<typename Vec<T>::type*>(lds + (rr + RPP * p) * LDK + kk) = v;
-            }
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<vec_t*>(lds + (rr + RPP * p) * LDK + kk) = regs[p];
         } else {
             const int rr = (t % TPK) * W, kk = t / TPK;
 #pragma unroll
-            for (int p = 0; p < NPT; ++p) {
-                typename Vec<T>::type v;
-#pragma unroll
-                for (int i = 0; i < W; ++i) v[i] = regs[W * p + i];
-                *reinterpret_cast<typename Vec<T>::type*>(lds + (kk + KPP * p) * LDR + rr) = v;
-            }
+            for (int p = 0; p < NPT; ++p) *reinterpret_cast<vec_t*>(lds + (kk + KPP * p) * LDR + rr) = regs[p];
         }
     }
 
@@ -172,7 +156,8 @@ gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    T ra[SA::NREG], rb[SB::NREG];
+    typename SA::vec_t ra[SA::NV];
+    typename SB::vec_t rb[SB::NV];
     SA::load(A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
     SB::load(B, g.ldb, n0, g.N, kbeg, kend, g.vecB, rb);
 
