@@ -168,12 +168,12 @@ def roofline_of(row, dtype_name):
         return dict(kernel=kernel_of(row["name"], row["ints"]), bound="hbm", achieved=round(ach, 1),
                     peak=HBM_PEAK / 1e9, unit="GB/s", frac=round(ach / (HBM_PEAK / 1e9), 4), traffic=traffic,
                     algorithmic_bytes=int(nbytes), algorithmic_flops=float(flops),
-                    avg_launch_ms=round(row["avg_ms"], 4), launches_per_step=row["launches"])
+                    avg_launch_ms=round(row["avg_ms"], 4), launches_in_timed_region=row["launches"])
     ach = flops / dur / 1e12
     return dict(kernel=kernel_of(row["name"], row["ints"]), bound="mfma", achieved=round(ach, 2),
                 peak=peak_f / 1e12, unit="TFLOP/s", frac=round(ach / (peak_f / 1e12), 4), traffic=traffic,
                 algorithmic_bytes=int(nbytes), algorithmic_flops=float(flops),
-                avg_launch_ms=round(row["avg_ms"], 4), launches_per_step=row["launches"])
+                avg_launch_ms=round(row["avg_ms"], 4), launches_in_timed_region=row["launches"])
 
 
 # ---------------------------------------------------------------------------------------------

@@ -965,7 +965,7 @@ inline bool params_ok(const mfc_cnx_params* p) {
            p->con_b && p->ls;
 }
 
-constexpr int64_t MAX_BLOCKS = 2048;
+static const int64_t MAX_BLOCKS = getenv("MFC_CNX_MAX_BLOCKS") ? atoll(getenv("MFC_CNX_MAX_BLOCKS")) : 2048;
 
 template <typename K, typename A>
 inline int launch_k(K kern, int64_t grid, size_t lds, hipStream_t st, const A& args) {

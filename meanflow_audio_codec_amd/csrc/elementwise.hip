@@ -248,6 +248,45 @@ __global__ void colsum_kernel(int64_t M, int64_t N, const T* X, int64_t ld, floa
         out[c] = accum ? out[c] + acc : acc;
     }
 }
+// 16-byte-vector variant: each thread owns VW consecutive columns, 4 rows in flight
+template <typename T, int VW>
+__global__ void __launch_bounds__(ET) colsum_vec_kernel(int64_t M, int64_t N, const T* X, int64_t ld, float scale,
+                                                        float* out, int accum) {
+    typedef T vt __attribute__((ext_vector_type(VW)));
+    const int64_t groups = N / VW;
+    for (int64_t gidx = blockIdx.x * (int64_t)ET + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * ET) {
+        const T* p = X + gidx * VW;
+        float acc[VW];
+#pragma unroll
+        for (int i = 0; i < VW; ++i) acc[i] = 0.f;
+        int64_t m = 0;
+        for (; m + 4 <= M; m += 4) {
+            vt v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const vt*>(p + (m + u) * ld);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < VW; ++i) {
+                    T e = v[u][i];
+                    acc[i] += St<T>::ld(&e);
+                }
+        }
+        for (; m < M; ++m) {
+            const vt v = *reinterpret_cast<const vt*>(p + m * ld);
+#pragma unroll
+            for (int i = 0; i < VW; ++i) {
+                T e = v[i];
+                acc[i] += St<T>::ld(&e);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VW; ++i) {
+            const float r = acc[i] * scale;
+            out[gidx * VW + i] = accum ? out[gidx * VW + i] + r : r;
+        }
+    }
+}
 
 template <typename T>
 __global__ void axpby_kernel(int64_t n, float a, const T* x, float b, const T* y, T* out) {
@@ -394,6 +433,17 @@ extern "C" int mfc_colsum(int dtype, int64_t M, int64_t N, const void* X, int64_
     if (!X || !out) return MFC_EFAULT;
     if (M <= 0 || N <= 0 || ld < N || !DT_OK(dtype)) return MFC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    const int vw = dtype == MFC_F32 ? 4 : 8;
+    const size_t es = dtype == MFC_F32 ? 4 : 2;
+    if (N % vw == 0 && (ld * es) % 16 == 0 && ((uintptr_t)X % 16) == 0 && N >= 4096) {
+        if (dtype == MFC_F32)
+            hipLaunchKernelGGL((colsum_vec_kernel<float, 4>), dim3(grid_for(N / 4)), dim3(ET), 0, st, M, N,
+                               (const float*)X, ld, scale, out, accumulate);
+        else
+            hipLaunchKernelGGL((colsum_vec_kernel<u16, 8>), dim3(grid_for(N / 8)), dim3(ET), 0, st, M, N,
+                               (const u16*)X, ld, scale, out, accumulate);
+        return mfc_launch_status();
+    }
     if (dtype == MFC_F32)
         hipLaunchKernelGGL(colsum_kernel<float>, dim3(grid_for(N)), dim3(ET), 0, st, M, N, (const float*)X, ld,
                            scale, out, accumulate);
