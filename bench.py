@@ -107,24 +107,34 @@ def algorithmic_work(name, ints, nn):
     return None
 
 
-def traffic_key(name, ints):
+def symbol_of(name, ints, nn):
+    """HIP kernel symbol (as rocprofv3 prints it, minus the namespace) of the main kernel behind one C-ABI call."""
     if name == "mfc_adamw":
-        return f"adamw_kernel n={ints[1]}"
+        return f"adamw_kernel<{'float' if ints[0] == 0 else 'unsigned short'}>"
     if name == "mfc_gemm":
-        return f"gemm M={ints[2]} N={ints[3]} K={ints[4]}"
+        dt, flags, M, N, K = ints[:5]
+        T = "float" if dt == 0 else "unsigned short"
+        tf = lambda b: "true" if b else "false"
+        return f"gemm_kernel<{T}, {32 if K <= 32 else 64}, {tf(flags & 1)}, {tf(flags & 2)}>"
     if name.startswith("mfc_cnx_"):
-        k = name.replace("mfc_", "")
-        k = {"cnx_bwd_main": "cnx_bwd_main_kernel"}.get(k, k + "_kernel")
-        return f"{k} R={ints[1]}"
-    return None
+        T = "float" if ints[0] == 0 else "unsigned short"
+        if name in ("mfc_cnx_stats", "mfc_cnx_apply"):
+            return f"cnx_fwd_kernel<{T}, {'true' if nn[2] else 'false'}, {0 if name == 'mfc_cnx_stats' else 1}>"
+        if name == "mfc_cnx_bwd_stats":
+            return f"cnx_bwd_kernel<{T}, 0>"
+        if name == "mfc_cnx_bwd_main":
+            return f"cnx_bwd_kernel<{T}, 1>"
+        return f"cnx_bwd_conv_kernel<{T}>"
+    return name.replace("mfc_", "") + "_kernel"
 
 
-def measured_traffic(name, ints):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json), or None."""
+def measured_traffic(symbol):
+    """average HBM bytes per launch of a kernel symbol from the committed rocprofv3 PMC passes, or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             tab = json.load(f)
-        return tab.get(traffic_key(name, ints))
+        e = tab.get(symbol)
+        return None if e is None else e["avg_hbm_bytes_per_launch"]
     except Exception:
         return None
 
@@ -155,25 +165,58 @@ def summarize_timing(records, steps):
 
 
 def roofline_of(row, dtype_name):
+    """fraction-of-roofline of ONE (call, shape) row -- used for the top_kernels listing."""
     w = algorithmic_work(row["name"], row["ints"], row["nn"])
     if w is None:
         return None
     nbytes, flops, dt = w
-    traffic = measured_traffic(row["name"], row["ints"])
     dur = row["avg_ms"] * 1e-3
     peak_f = MFMA_PEAK["f32" if dt == 0 else "bf16"]
-    t_h, t_f = nbytes / HBM_PEAK, flops / peak_f
-    if t_h >= t_f:
-        ach = nbytes / dur / 1e9
-        return dict(kernel=kernel_of(row["name"], row["ints"]), bound="hbm", achieved=round(ach, 1),
-                    peak=HBM_PEAK / 1e9, unit="GB/s", frac=round(ach / (HBM_PEAK / 1e9), 4), traffic=traffic,
-                    algorithmic_bytes=int(nbytes), algorithmic_flops=float(flops),
-                    avg_launch_ms=round(row["avg_ms"], 4), launches_in_timed_region=row["launches"])
-    ach = flops / dur / 1e12
-    return dict(kernel=kernel_of(row["name"], row["ints"]), bound="mfma", achieved=round(ach, 2),
-                peak=peak_f / 1e12, unit="TFLOP/s", frac=round(ach / (peak_f / 1e12), 4), traffic=traffic,
-                algorithmic_bytes=int(nbytes), algorithmic_flops=float(flops),
-                avg_launch_ms=round(row["avg_ms"], 4), launches_in_timed_region=row["launches"])
+    if nbytes / HBM_PEAK >= flops / peak_f:
+        return dict(bound="hbm", frac=round(nbytes / dur / HBM_PEAK, 4))
+    return dict(bound="mfma", frac=round(flops / dur / peak_f, 4))
+
+
+def dominant_roofline(rows, ms_per_step, steps):
+    """The `roofline` object: the kernel SYMBOL with the largest total time in the timed region (all its
+    launches and shapes, which is what `rocprofv3 --kernel-trace --stats` averages), algorithmic bytes or
+    FLOP summed over those launches divided by their summed HIP-event durations."""
+    sym = {}
+    for r in rows:
+        w = algorithmic_work(r["name"], r["ints"], r["nn"])
+        s = symbol_of(r["name"], r["ints"], r["nn"])
+        e = sym.setdefault(s, dict(ms=0.0, launches=0, bytes=0.0, flops=0.0, dt=1, modelled=True))
+        e["ms"] += r["total_ms"]
+        e["launches"] += r["launches"]
+        if w is None:
+            e["modelled"] = False
+        else:
+            e["bytes"] += w[0] * r["launches"]
+            e["flops"] += w[1] * r["launches"]
+            e["dt"] = w[2]
+    best = None
+    for s, e in sorted(sym.items(), key=lambda kv: -kv[1]["ms"]):
+        if e["modelled"]:
+            best = (s, e)
+            break
+    if best is None:
+        return None
+    s, e = best
+    dur = e["ms"] * 1e-3
+    peak_f = MFMA_PEAK["f32" if e["dt"] == 0 else "bf16"]
+    out = dict(kernel=s, avg_launch_ms=round(e["ms"] / e["launches"], 4), launches_in_timed_region=e["launches"],
+               share_of_step=round(e["ms"] / steps / ms_per_step, 4),
+               algorithmic_bytes_per_launch=int(e["bytes"] / e["launches"]),
+               algorithmic_flops_per_launch=float(e["flops"] / e["launches"]), traffic=measured_traffic(s))
+    if e["bytes"] / HBM_PEAK >= e["flops"] / peak_f:
+        ach = e["bytes"] / dur / 1e9
+        out.update(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
+                   frac=round(ach / (HBM_PEAK / 1e9), 4))
+    else:
+        ach = e["flops"] / dur / 1e12
+        out.update(bound="mfma", achieved=round(ach, 2), peak=peak_f / 1e12, unit="TFLOP/s",
+                   frac=round(ach / (peak_f / 1e12), 4))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
@@ -343,20 +386,13 @@ def main():
     if rank == 0:
         # per-kernel timing over the timed region (HIP events on the launch stream)
         rows = summarize_timing(records, args.steps)
-        dom = None
-        for row in rows:
-            rf = roofline_of(row, args.dtype)
-            if rf is not None:
-                dom = rf
-                dom["share_of_step"] = round(row["per_step_ms"] / ms_per_step, 4)
-                break
-        out["roofline"] = dom
+        out["roofline"] = dominant_roofline(rows, ms_per_step, args.steps)
         out["sum_kernel_ms_per_step"] = round(sum(r["per_step_ms"] for r in rows), 2)
         out["launches_per_step"] = int(sum(r["launches"] for r in rows) / max(1, args.steps))
         out["top_kernels"] = [
             dict(kernel=kernel_of(r["name"], r["ints"]), per_step_ms=round(r["per_step_ms"], 3),
                  launches=r["launches"], avg_ms=round(r["avg_ms"], 4),
-                 **({k: v for k, v in (roofline_of(r, args.dtype) or {}).items() if k in ("bound", "frac")}))
+                 **(roofline_of(r, args.dtype) or {}))
             for r in rows[:40]]
         flops_alg = 4.0 * conv_flow_flops_fwd(D, wl["blocks"], wl["cond"])
         out["step_model"] = {"algorithmic_gflop_per_sample": round(flops_alg / 1e9, 2),
