@@ -1,0 +1,35 @@
+"""CPU: the bench's work model and symbol mapping (no GPU needed)."""
+import json
+import math
+import pathlib
+
+import bench
+
+
+def test_flop_model_matches_survey():
+    # 48.16 GFLOP fwd per sample at D = 392704; CI shape 3.94 GFLOP at D = 32256
+    assert abs(bench.conv_flow_flops_fwd(767 * 512) / 1e9 - 48.16) < 0.05
+    assert abs(bench.conv_flow_flops_fwd(63 * 512) / 1e9 - 3.94) < 0.02
+
+
+def test_algorithmic_bytes():
+    # MDCT forward per clip: 4T + 4 n_frames N = 2 357 248 B
+    nb, fl, _ = bench.algorithmic_work("mfc_mdct_fwd", (1, 196608, 196608, 512, 256), ())
+    assert nb == 2357248
+    nb, _, _ = bench.algorithmic_work("mfc_mdct_inv", (1, 767, 512, 256, 197120), ())
+    assert nb == 2359296
+    # AdamW with bf16 gradient and bf16 working copy: 28 B / parameter
+    nb, _, _ = bench.algorithmic_work("mfc_adamw", (1, 1000, 3), (True, True, True, True, True))
+    assert nb == 28000
+    nb, fl, dt = bench.algorithmic_work("mfc_gemm", (1, 0, 128, 6270016, 128) + (0,) * 7, (True,) * 9)
+    assert fl == 2.0 * 128 * 6270016 * 128 and dt == 1
+
+
+def test_symbols_and_traffic_table():
+    s = bench.symbol_of("mfc_adamw", (1, 802562048, 3), (True,) * 5)
+    assert s == "adamw_kernel<unsigned short>"
+    tab = json.loads((pathlib.Path(bench.ROOT) / "profiles" / "r01_pmc_traffic.json").read_text())
+    assert s in tab and tab[s]["avg_hbm_bytes_per_launch"] > 1e9
+    assert bench.measured_traffic(s) == tab[s]["avg_hbm_bytes_per_launch"]
+    assert bench.symbol_of("mfc_cnx_bwd_main", (1, 128, 626), (True,) * 8) == "cnx_bwd_kernel<unsigned short, 1>"
+    assert bench.symbol_of("mfc_gemm", (0, 3, 4, 4, 16) + (0,) * 7, ()) == "gemm_kernel<float, 32, true, true>"
