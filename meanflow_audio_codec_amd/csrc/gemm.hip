@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, GT = 256;
+constexpr int BN = 128, GT = 256;   // BM is a template parameter (128, or 64 for remainder rows)
 constexpr int ldk_of(int BK, int es) { return BK + 16 / es; }   // K-contiguous tile [128][LDK]: +16 B pad
 constexpr int ldr_of(int es) { return es == 4 ? 132 : 144; }     // row-contiguous tile [BK][LDR]
 constexpr int tile_elems(int BK, int es) {
@@ -40,6 +40,7 @@ struct GemmArgs {
     int vecC;        // 16-byte row-contiguous C (and R) accesses legal
     int m_fast;      // blockIdx.x walks M tiles (else N tiles)
     float* ln_rstd;  // MFC_GEMM_LN16: per-(row, 16-column group) 1/sigma, or null
+    int64_t m_base;  // first row handled by this launch (rows below belong to another launch)
 };
 
 template <typename T> struct Vec;   // 16-byte global vector
@@ -64,14 +65,14 @@ __device__ inline typename Vec<T>::type loadv(const T* p, int64_t valid, bool ve
 // registers stay packed 16-byte vectors (bf16: 8 elements in 4 VGPRs).
 //  KC = true : source is K-contiguous   src[row*ld + k]   -> LDS tile [128][LDK]
 //  KC = false: source is row-contiguous src[k*ld + row]   -> LDS tile [BK][LDR] (no transpose on the way in)
-template <typename T, int BK, bool KC> struct Stage {
+template <typename T, int BK, bool KC, int ROWS = 128> struct Stage {
     typedef typename Vec<T>::type vec_t;
     static constexpr int W = Vec<T>::W;
     static constexpr int LDK = ldk_of(BK, sizeof(T));
     static constexpr int LDR = ldr_of(sizeof(T));
-    static constexpr int TPR = BK / W, RPP = GT / TPR, NP = 128 / RPP;       // KC geometry
-    static constexpr int TPK = 128 / W, KPP = GT / TPK, NPT = BK / KPP;     // !KC geometry
-    static constexpr int NV = KC ? NP : NPT;                                // vectors per thread
+    static constexpr int TPR = BK / W, RPP = GT / TPR, NP = (ROWS + RPP - 1) / RPP;    // KC geometry
+    static constexpr int TPK = ROWS / W, KPP = GT / TPK, NPT = (BK + KPP - 1) / KPP;  // !KC geometry
+    static constexpr int NV = KC ? NP : NPT;                                          // vectors per thread
 
     __device__ static inline void load(const T* src, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
                                        int64_t kend, bool vec, vec_t* regs) {
@@ -84,14 +85,14 @@ template <typename T, int BK, bool KC> struct Stage {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int64_t row = row0 + rr + RPP * p, k = k0 + kk;
-                regs[p] = (row < nrows && k < kend) ? loadv<T>(src + row * ld + k, kend - k, vec) : z;
+                regs[p] = (rr + RPP * p < ROWS && row < nrows && k < kend) ? loadv<T>(src + row * ld + k, kend - k, vec) : z;
             }
         } else {
             const int rr = (t % TPK) * W, kk = t / TPK;
 #pragma unroll
             for (int p = 0; p < NPT; ++p) {
                 const int64_t k = k0 + kk + KPP * p, row = row0 + rr;
-                regs[p] = (k < kend && row < nrows) ? loadv<T>(src + k * ld + row, nrows - row, vec) : z;
+                regs[p] = (kk + KPP * p < BK && k < kend && row < nrows) ? loadv<T>(src + k * ld + row, nrows - row, vec) : z;
             }
         }
     }
@@ -100,11 +101,13 @@ template <typename T, int BK, bool KC> struct Stage {
         if constexpr (KC) {
             const int kk = (t % TPR) * W, rr = t / TPR;
 #pragma unroll
-            for (int p = 0; p < NP; ++p) *reinterpret_cast<vec_t*>(lds + (rr + RPP * p) * LDK + kk) = regs[p];
+            for (int p = 0; p < NP; ++p)
+                if (rr + RPP * p < ROWS) *reinterpret_cast<vec_t*>(lds + (rr + RPP * p) * LDK + kk) = regs[p];
         } else {
             const int rr = (t % TPK) * W, kk = t / TPK;
 #pragma unroll
-            for (int p = 0; p < NPT; ++p) *reinterpret_cast<vec_t*>(lds + (kk + KPP * p) * LDR + rr) = regs[p];
+            for (int p = 0; p < NPT; ++p)
+                if (kk + KPP * p < BK) *reinterpret_cast<vec_t*>(lds + (kk + KPP * p) * LDR + rr) = regs[p];
         }
     }
 
@@ -125,34 +128,35 @@ template <typename T, int BK, bool KC> struct Stage {
     }
 };
 
-template <typename T, int BK, bool TA, bool TB>
+template <typename T, int BK, bool TA, bool TB, int BMT>
 __global__ void __launch_bounds__(GT)
 gemm_kernel(GemmArgs g) {
+    constexpr int MI = BMT / 32;          // 16-row MFMA tiles per wave along M (waves are 2 x 2)
     // operand tiles: [128][LDK] when the source is K-contiguous, [BK][LDR] when it is row-contiguous
     constexpr int TE = tile_elems(BK, sizeof(T));
     __shared__ __attribute__((aligned(16))) T lds[2 * TE];
     T* As = lds;
     T* Bs = lds + TE;
     typedef typename Frag<T>::type frag_t;
-    typedef Stage<T, BK, !TA> SA;   // A: K-contiguous when not transposed ([M][K])
+    typedef Stage<T, BK, !TA, BMT> SA;   // A: K-contiguous when not transposed ([M][K])
     typedef Stage<T, BK, TB> SB;    // B: K-contiguous when transposed ([N][K])
 
     const T* A = (const T*)g.A;
     const T* B = (const T*)g.B;
     // M-tile index fastest when it fits: the M-tiles of one N-tile run back to back, so the streamed
     // weight tile is fetched from HBM once and re-read from L2 / Infinity Cache
-    const int64_t m0 = (int64_t)(g.m_fast ? blockIdx.x : blockIdx.y) * BM;
+    const int64_t m0 = g.m_base + (int64_t)(g.m_fast ? blockIdx.x : blockIdx.y) * BMT;
     const int64_t n0 = (int64_t)(g.m_fast ? blockIdx.y : blockIdx.x) * BN;
     const int64_t kbeg = (int64_t)blockIdx.z * g.kchunk;
     const int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave >> 1) * (BMT / 2), wn = (wave & 1) * 64;
     const int q = lane >> 4, r = lane & 15;
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -171,15 +175,15 @@ gemm_kernel(GemmArgs g) {
         }
 #pragma unroll
         for (int c = 0; c < BK / 16; ++c) {
-            frag_t af[4], bf[4];
+            frag_t af[MI], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
                 af[i] = SA::fetch(As, wm + 16 * i, c, q, r);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 bf[j] = SB::fetch(Bs, wn + 16 * j, c, q, r);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mma16(acc[i][j], af[i], bf[j]);
         }
@@ -197,7 +201,7 @@ gemm_kernel(GemmArgs g) {
         float* cs = reinterpret_cast<float*>(lds) + wave * (16 * CSS);
         const int lr = lane >> 2, lc = (lane & 3) * 16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -273,7 +277,7 @@ gemm_kernel(GemmArgs g) {
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t col = n0 + wn + 16 * j + r;
@@ -326,24 +330,43 @@ gemm_epilogue_kernel(const float* ws, int64_t M, int64_t N, T* C, int64_t ldc,
     }
 }
 
-template <typename T, int BK>
+template <typename T, int BK, int BMT>
 void launch_bk(bool ta, bool tb, dim3 grid, const GemmArgs& g, hipStream_t st) {
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, BK, false, false>), grid, dim3(GT), 0, st, g);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, BK, false, true>), grid, dim3(GT), 0, st, g);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, BK, true, false>), grid, dim3(GT), 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<T, BK, true, true>), grid, dim3(GT), 0, st, g);
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, BK, false, false, BMT>), grid, dim3(GT), 0, st, g);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, BK, false, true, BMT>), grid, dim3(GT), 0, st, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, BK, true, false, BMT>), grid, dim3(GT), 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<T, BK, true, true, BMT>), grid, dim3(GT), 0, st, g);
 }
 
-template <typename T>
-int launch(int flags, GemmArgs g, int bk, int splitk, int gelu, int64_t act_rows, hipStream_t st) {
-    const int64_t tm = ceil_div64(g.M, BM), tn = ceil_div64(g.N, BN);
+// one launch over rows [m_base, m_base + rows) with BMT-row tiles
+template <typename T, int BMT>
+int launch_rows(int flags, GemmArgs g, int bk, int splitk, int64_t m_base, int64_t rows, hipStream_t st) {
+    const int64_t tm = ceil_div64(rows, BMT), tn = ceil_div64(g.N, BN);
+    g.m_base = m_base;
+    g.M = m_base + rows;          // rows >= M are masked; rows < m_base are never touched by this launch
     g.m_fast = (tn <= 65535) ? 1 : 0;
     if (!g.m_fast && tm > 65535) return MFC_EINVAL;
     dim3 grid((unsigned)(g.m_fast ? tm : tn), (unsigned)(g.m_fast ? tn : tm), (unsigned)splitk);
     const bool ta = flags & MFC_GEMM_TRANS_A, tb = flags & MFC_GEMM_TRANS_B;
-    if (bk == 32) launch_bk<T, 32>(ta, tb, grid, g, st);
-    else launch_bk<T, 64>(ta, tb, grid, g, st);
-    int rc = mfc_launch_status();
+    if (bk == 32) launch_bk<T, 32, BMT>(ta, tb, grid, g, st);
+    else launch_bk<T, 64, BMT>(ta, tb, grid, g, st);
+    return mfc_launch_status();
+}
+
+template <typename T>
+int launch(int flags, GemmArgs g, int bk, int splitk, int gelu, int64_t act_rows, hipStream_t st) {
+    // 128-row tiles for the bulk; a remainder of <= 64 rows (row-stacked [primal; tangent] batches such as
+    // 128 + 64) runs as a second launch with 64-row tiles instead of a half-empty 128-row tile
+    const int64_t M = g.M;
+    const int64_t tail = M % 128;
+    int rc = MFC_OK;
+    if (tail > 0 && tail <= 64) {
+        if (M > tail) rc = launch_rows<T, 128>(flags, g, bk, splitk, 0, M - tail, st);
+        if (!rc) rc = launch_rows<T, 64>(flags, g, bk, splitk, M - tail, tail, st);
+    } else {
+        rc = launch_rows<T, 128>(flags, g, bk, splitk, 0, M, st);
+    }
+    g.M = M;
     if (rc) return rc;
     if (g.ws) {
         int64_t blocks = ceil_div64(g.M * g.N, 256);

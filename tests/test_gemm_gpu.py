@@ -20,7 +20,7 @@ def _ref(A, B, ta, tb, bias, bias_rows, alpha, R, beta):
 
 
 SHAPES = [(128, 128, 32), (4, 16, 20), (130, 257, 100), (256, 384, 96), (37, 515, 1030), (300, 64, 4099),
-          (1, 1, 1), (129, 129, 33)]
+          (1, 1, 1), (129, 129, 33), (192, 160, 72), (64, 128, 64), (448, 48, 200), (200, 32, 40)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
