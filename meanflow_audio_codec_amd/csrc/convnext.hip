@@ -551,7 +551,7 @@ __device__ inline typename Frag<T>::type pix_k_frag(const T* tile, int q, int r)
 // MODE 0: dq[r,ch] = sum dy*g1, dbeta += sum dy.
 // MODE 1: dc1 + small-parameter gradients (con_w, con_b, ls, exp_w, exp_b, conv_b).
 template <typename T, int MODE>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, sizeof(T) == 2 ? 2 : 1)   // bf16: <= 256 registers, two waves per SIMD
 cnx_bwd_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Frag<T>::type frag_t;
@@ -576,7 +576,7 @@ cnx_bwd_kernel(BwdArgs a) {
     float dqp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dbeta[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     // MODE 1 accumulators
     f32x4 aWp[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, aWe[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-    float dls[4] = {0.f, 0.f, 0.f, 0.f}, dbp[4] = {0.f, 0.f, 0.f, 0.f}, dbc[4] = {0.f, 0.f, 0.f, 0.f};
+    float dls[4] = {0.f, 0.f, 0.f, 0.f};      // (con_b and conv_b gradients: cnx_bwd_conv_kernel)
     float dbe[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
     auto flush_row = [&](int64_t r) {
@@ -677,7 +677,7 @@ cnx_bwd_kernel(BwdArgs a) {
                     mma16(p1, w.wp[j], yf[j]);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { dls[i] += dov[i] * p1[i]; dbp[i] += dp1[i]; }
+                for (int i = 0; i < 4; ++i) dls[i] += dov[i] * p1[i];
                 // d gelu / d expand
                 frag_t def[2];
                 f32x4 dn1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -695,11 +695,7 @@ cnx_bwd_kernel(BwdArgs a) {
                 }
                 float dn[4] = {dn1[0], dn1[1], dn1[2], dn1[3]}, dc[4];
                 ln_bwd_a(dn, f.n1, f.rho1, dc);
-                if (ok) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) dbc[i] += dc[i];
-                    st4((T*)a.dc1 + ((r * s + gy) * (int64_t)s + gx) * 16 + 4 * q, dc);
-                }
+                if (ok) st4((T*)a.dc1 + ((r * s + gy) * (int64_t)s + gx) * 16 + 4 * q, dc);
                 // weight gradients contract over the 16 pixels of the row: one batched transpose
                 // (pixel-on-lane -> pixel-as-k) of y0, y1, dp1, n1, de0, de1 through the wave scratch
                 *reinterpret_cast<frag_t*>(l.ws + (0 * 16 + m) * CS + 4 * q) = yf[0];
@@ -741,12 +737,8 @@ cnx_bwd_kernel(BwdArgs a) {
             }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float v1 = red_m(dls[i]), v2 = red_m(dbp[i]), v3 = red_m(dbc[i]);
-            if (m == 0) {
-                atomicAdd(a.g.ls + 4 * q + i, v1);
-                atomicAdd(a.g.con_b + 4 * q + i, v2);
-                atomicAdd(a.g.conv_b + 4 * q + i, v3);
-            }
+            const float v1 = red_m(dls[i]);
+            if (m == 0) atomicAdd(a.g.ls + 4 * q + i, v1);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float v = red_m(dbe[j][i]);
@@ -782,6 +774,7 @@ cnx_bwd_conv_kernel(BwdArgs a) {
     for (int t = 0; t < 9; ++t) aWc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dscp[4] = {0.f, 0.f, 0.f, 0.f}, dshp[4] = {0.f, 0.f, 0.f, 0.f};
     float sc4[4] = {0.f, 0.f, 0.f, 0.f};
+    float dsum[4] = {0.f, 0.f, 0.f, 0.f}, dcsum[4] = {0.f, 0.f, 0.f, 0.f};   // -> d con_b (x ls), d conv_b
 
     auto flush_row = [&](int64_t r) {
 #pragma unroll
@@ -864,7 +857,15 @@ cnx_bwd_conv_kernel(BwdArgs a) {
                     const frag_t ad = *reinterpret_cast<const frag_t*>(
                         l.aux + ((y + 2 - i) * HW + (m + 2 - j)) * CS + 4 * q);
                     mma16(dh, wcT[i * 3 + j], ad);
+                    if (i == 1 && j == 1) {   // centre tap: this lane's own dc1 (zero outside the image)
+                        float dcv[4];
+                        unfrag(ad, dcv);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dcsum[k] += dcv[k];
+                    }
                 }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dsum[k] += dov[k];
             // dWc[tap][ic][oc] += sum_pixels h2[p + tap][ic] dc1[p][oc]
             {
                 const frag_t bd = pix_k_frag<T>(l.aux + ((y + 1) * HW + 1) * CS, q, m);
@@ -893,6 +894,14 @@ cnx_bwd_conv_kernel(BwdArgs a) {
         }
     }
     if (rcur >= 0) flush_row(rcur);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float v1 = red_m(dsum[i]), v2 = red_m(dcsum[i]);
+        if (m == 0) {
+            atomicAdd(a.g.con_b + 4 * q + i, v1 * a.p.ls[4 * q + i]);
+            atomicAdd(a.g.conv_b + 4 * q + i, v2);
+        }
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
