@@ -84,6 +84,10 @@ int mfc_mdct_inv(const float* X, int64_t B, int64_t n_frames, int N, int hop,
                                 group of 16 output columns (one NHWC pixel of the ConvNeXt map);
                                 1/sigma of each group goes to ln_rstd[row*(N/16) + group].  Needs
                                 N % 16 == 0, 16-byte aligned C, no split-K.                    */
+#define MFC_GEMM_LN16T 32    /* with MFC_GEMM_LN16: rows >= bias_rows are tangents of the rows
+                                (r - bias_rows) and receive the tangent of that LayerNorm,
+                                rho (xd - mean(xd) - n mean(n (xd - mean(xd)))); needs
+                                M - bias_rows <= bias_rows.                                     */
 
 /* C[M,N] = alpha * (op(A)[M,K] . op(B)[K,N] + bias[N] on rows < bias_rows)
  *          + beta_res * R[M,N]

@@ -17,7 +17,7 @@ LIB_PATH = _HERE / "csrc" / "libmfc.so"
 HEADER = _HERE.parent / "include" / "mfc.h"
 
 MFC_F32, MFC_BF16 = 0, 1
-GEMM_TRANS_A, GEMM_TRANS_B, GEMM_ACCUM, GEMM_GELU, GEMM_LN16 = 1, 2, 4, 8, 16
+GEMM_TRANS_A, GEMM_TRANS_B, GEMM_ACCUM, GEMM_GELU, GEMM_LN16, GEMM_LN16T = 1, 2, 4, 8, 16, 32
 
 _ERR = {-22: "MFC_EINVAL (bad shape/argument)", -38: "MFC_ENOSYS (unsupported)",
         -14: "MFC_EFAULT (null pointer)", -5: "MFC_EHIP (HIP launch error)"}

@@ -291,6 +291,16 @@ __device__ inline TileCoord tile_coord(const Geo& g, int64_t t) {
     c.x0 = (ti % g.tilesX) * TW;
     return c;
 }
+// the tile after c in a workgroup's contiguous chunk (the 64-bit divisions of tile_coord cost more
+// scalar instructions per tile than a whole tile row of the chain costs vector ones)
+__device__ inline TileCoord tile_next(const Geo& g, TileCoord c) {
+    c.x0 += TW;
+    if (c.x0 >= g.tilesX * TW) {
+        c.x0 = 0; c.y0 += TH;
+        if (c.y0 >= g.tilesY * TH) { c.y0 = 0; c.r += 1; }
+    }
+    return c;
+}
 
 // Per-lane weights / constants of the forward chain.  Lane (q, m): m = pixel
 // within the tile row, channel constants are those of channels 4q..4q+3.
@@ -437,9 +447,11 @@ cnx_fwd_kernel(FwdArgs a) {
     };
 
     HaloRaw<T, JVP> raw;
-    if (t0 < t1) { const TileCoord c = tile_coord(a.geo, t0); halo_load<T, JVP>(raw, h0, h0d, a.rho, c.r, s, c.y0, c.x0); }
+    TileCoord tnext = tile_coord(a.geo, t0 < t1 ? t0 : 0);
+    if (t0 < t1) halo_load<T, JVP>(raw, h0, h0d, a.rho, tnext.r, s, tnext.y0, tnext.x0);
     for (int64_t t = t0; t < t1; ++t) {
-        const TileCoord tc = tile_coord(a.geo, t);
+        const TileCoord tc = tnext;
+        tnext = tile_next(a.geo, tc);
         const int64_t r = tc.r;
         const int y0 = tc.y0, x0 = tc.x0;
         __syncthreads();  // previous tile fully consumed
@@ -460,7 +472,7 @@ cnx_fwd_kernel(FwdArgs a) {
         }
         if (!(a.dbg & 2) || t == t0) halo_commit<T, JVP>(l, raw);
         __syncthreads();
-        if (t + 1 < t1 && !(a.dbg & 2)) { const TileCoord c = tile_coord(a.geo, t + 1); halo_load<T, JVP>(raw, h0, h0d, a.rho, c.r, s, c.y0, c.x0); }
+        if (t + 1 < t1 && !(a.dbg & 2)) halo_load<T, JVP>(raw, h0, h0d, a.rho, tnext.r, s, tnext.y0, tnext.x0);
         const int gx = x0 + m;
 #pragma unroll 1
         for (int ri = 0; ri < ((a.dbg & 1) ? 0 : RPW); ++ri) {
@@ -603,13 +615,14 @@ cnx_bwd_kernel(BwdArgs a) {
     };
     HaloRaw<T, false> raw;
     frag_t dnext[RPW];
+    TileCoord tnext = tile_coord(a.geo, t0 < t1 ? t0 : 0);
     if (t0 < t1) {
-        const TileCoord c = tile_coord(a.geo, t0);
-        halo_load<T, false>(raw, h0, nullptr, nullptr, c.r, s, c.y0, c.x0);
-        load_dout(dnext, c);
+        halo_load<T, false>(raw, h0, nullptr, nullptr, tnext.r, s, tnext.y0, tnext.x0);
+        load_dout(dnext, tnext);
     }
     for (int64_t t = t0; t < t1; ++t) {
-        const TileCoord tc = tile_coord(a.geo, t);
+        const TileCoord tc = tnext;
+        tnext = tile_next(a.geo, tc);
         const int64_t r = tc.r;
         const int y0 = tc.y0, x0 = tc.x0;
         const int gx = x0 + m;
@@ -633,9 +646,8 @@ cnx_bwd_kernel(BwdArgs a) {
         halo_commit<T, false>(l, raw);
         __syncthreads();
         if (t + 1 < t1) {
-            const TileCoord c = tile_coord(a.geo, t + 1);
-            halo_load<T, false>(raw, h0, nullptr, nullptr, c.r, s, c.y0, c.x0);
-            load_dout(dnext, c);
+            halo_load<T, false>(raw, h0, nullptr, nullptr, tnext.r, s, tnext.y0, tnext.x0);
+            load_dout(dnext, tnext);
         }
 #pragma unroll 1
         for (int ri = 0; ri < RPW; ++ri) {
@@ -805,14 +817,15 @@ cnx_bwd_conv_kernel(BwdArgs a) {
     HaloRaw<T, false> raw, rawd;
     frag_t dnext[RPW], hnext[RPW];
     float rnext[RPW];
+    TileCoord tnext = tile_coord(a.geo, t0 < t1 ? t0 : 0);
     if (t0 < t1) {
-        const TileCoord c = tile_coord(a.geo, t0);
-        halo_load<T, false>(raw, h0, nullptr, nullptr, c.r, s, c.y0, c.x0);
-        halo_load<T, false>(rawd, dc1, nullptr, nullptr, c.r, s, c.y0, c.x0);
-        load_centre(dnext, hnext, rnext, c);
+        halo_load<T, false>(raw, h0, nullptr, nullptr, tnext.r, s, tnext.y0, tnext.x0);
+        halo_load<T, false>(rawd, dc1, nullptr, nullptr, tnext.r, s, tnext.y0, tnext.x0);
+        load_centre(dnext, hnext, rnext, tnext);
     }
     for (int64_t t = t0; t < t1; ++t) {
-        const TileCoord tc = tile_coord(a.geo, t);
+        const TileCoord tc = tnext;
+        tnext = tile_next(a.geo, tc);
         const int64_t r = tc.r;
         const int y0 = tc.y0, x0 = tc.x0;
         const int gx = x0 + m;
@@ -833,10 +846,9 @@ cnx_bwd_conv_kernel(BwdArgs a) {
         halo_commit_raw<T>(l.aux, rawd);
         __syncthreads();
         if (t + 1 < t1) {
-            const TileCoord c = tile_coord(a.geo, t + 1);
-            halo_load<T, false>(raw, h0, nullptr, nullptr, c.r, s, c.y0, c.x0);
-            halo_load<T, false>(rawd, dc1, nullptr, nullptr, c.r, s, c.y0, c.x0);
-            load_centre(dnext, hnext, rnext, c);
+            halo_load<T, false>(raw, h0, nullptr, nullptr, tnext.r, s, tnext.y0, tnext.x0);
+            halo_load<T, false>(rawd, dc1, nullptr, nullptr, tnext.r, s, tnext.y0, tnext.x0);
+            load_centre(dnext, hnext, rnext, tnext);
         }
 #pragma unroll 1
         for (int ri = 0; ri < RPW; ++ri) {

@@ -15,6 +15,7 @@
 // lane from K-contiguous LDS tiles, so one staging/addressing scheme serves
 // both.  fp32 accumulate always.
 #include "mfc_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -128,6 +129,79 @@ template <typename T, int BK, bool KC, int ROWS = 128> struct Stage {
     }
 };
 
+// store 16 consecutive columns of one row: v already holds alpha*(acc + bias); adds beta*R and the
+// ACCUM read-modify-write, writes one (fp32: four) 16-byte vector(s)
+template <typename T>
+__device__ inline void store_row16(const GemmArgs& g, int64_t row, int64_t col0, float v[16]) {
+    T* cp = (T*)g.C + row * g.ldc + col0;
+    const T* R = (const T*)g.R;
+    if constexpr (sizeof(T) == 4) {
+        if (R) {
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(R + row * g.ldr + col0 + 4 * k4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[4 * k4 + k] += g.beta * t[k];
+            }
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            f32x4 t = f32x4{v[4 * k4], v[4 * k4 + 1], v[4 * k4 + 2], v[4 * k4 + 3]};
+            if (g.accum) t += *reinterpret_cast<const f32x4*>(cp + 4 * k4);
+            *reinterpret_cast<f32x4*>(cp + 4 * k4) = t;
+        }
+    } else {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        if (R) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const s16x8 t = *reinterpret_cast<const s16x8*>(R + row * g.ldr + col0 + 8 * h);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[8 * h + k] += g.beta * bf16_to_f32((u16)t[k]);
+            }
+        }
+        if (g.accum) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const s16x8 t = *reinterpret_cast<const s16x8*>(cp + 8 * h);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[8 * h + k] += bf16_to_f32((u16)t[k]);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const u32x4 t = {pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                             pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+            *reinterpret_cast<u32x4*>(cp + 8 * h) = t;
+        }
+    }
+}
+
+// LayerNorm (no affine, eps 1e-6) over the 16 values of one pixel held by one lane
+__device__ inline float ln16_lane(float v[16]) {
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { sum += v[k]; sq += v[k] * v[k]; }
+    const float mean = sum * (1.0f / 16.0f);
+    const float rho = rsqrtf(fmaxf(0.0f, sq * (1.0f / 16.0f) - mean * mean) + 1e-6f);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = (v[k] - mean) * rho;
+    return rho;
+}
+// its tangent: nd = rho (xd - mean(xd) - n mean(n (xd - mean(xd))))   (n, rho: the primal's output)
+__device__ inline void ln16_tangent_lane(float xd[16], const float n[16], float rho) {
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += xd[k];
+    const float md = sum * (1.0f / 16.0f);
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { xd[k] -= md; dot += n[k] * xd[k]; }
+    dot *= (1.0f / 16.0f);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) xd[k] = rho * (xd[k] - n[k] * dot);
+}
+
 template <typename T, int BK, bool TA, bool TB, int BMT>
 __global__ void __launch_bounds__(GT)
 gemm_kernel(GemmArgs g) {
@@ -222,56 +296,9 @@ gemm_kernel(GemmArgs g) {
                 for (int k = 0; k < 16; ++k) v[k] = (v[k] + (hb ? g.bias[col0 + k] : 0.f)) * g.alpha;
                 if (g.ln_rstd && row < g.bias_rows) {
                     // fused first LayerNorm of the ConvNeXt block: this lane holds one pixel's 16 channels
-                    float sum = 0.f, sq = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) { sum += v[k]; sq += v[k] * v[k]; }
-                    const float mean = sum * (1.0f / 16.0f);
-                    const float rho = rsqrtf(fmaxf(0.0f, sq * (1.0f / 16.0f) - mean * mean) + 1e-6f);
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) v[k] = (v[k] - mean) * rho;
-                    g.ln_rstd[row * (g.N >> 4) + (col0 >> 4)] = rho;
+                    g.ln_rstd[row * (g.N >> 4) + (col0 >> 4)] = ln16_lane(v);
                 }
-                T* cp = C + row * g.ldc + col0;
-                if constexpr (sizeof(T) == 4) {
-                    if (R) {
-#pragma unroll
-                        for (int k4 = 0; k4 < 4; ++k4) {
-                            const f32x4 t = *reinterpret_cast<const f32x4*>(R + row * g.ldr + col0 + 4 * k4);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) v[4 * k4 + k] += g.beta * t[k];
-                        }
-                    }
-#pragma unroll
-                    for (int k4 = 0; k4 < 4; ++k4) {
-                        f32x4 t = f32x4{v[4 * k4], v[4 * k4 + 1], v[4 * k4 + 2], v[4 * k4 + 3]};
-                        if (g.accum) t += *reinterpret_cast<const f32x4*>(cp + 4 * k4);
-                        *reinterpret_cast<f32x4*>(cp + 4 * k4) = t;
-                    }
-                } else {
-                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                    if (R) {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const s16x8 t = *reinterpret_cast<const s16x8*>(R + row * g.ldr + col0 + 8 * h);
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) v[8 * h + k] += g.beta * bf16_to_f32((u16)t[k]);
-                        }
-                    }
-                    if (g.accum) {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const s16x8 t = *reinterpret_cast<const s16x8*>(cp + 8 * h);
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) v[8 * h + k] += bf16_to_f32((u16)t[k]);
-                        }
-                    }
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const u32x4 t = {pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
-                                         pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
-                        *reinterpret_cast<u32x4*>(cp + 8 * h) = t;
-                    }
-                }
+                store_row16<T>(g, row, col0, v);
             }
         }
         return;
@@ -298,6 +325,275 @@ gemm_kernel(GemmArgs g) {
                 }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// N-streaming variant for the skinny products of the ConvNeXt flow (bf16, NN, K = 128, M <= 256,
+// N in the millions): the whole A operand lives in registers as MFMA fragments for the lifetime of a
+// persistent workgroup, which walks 64-column tiles of B / C.  Every byte of B is read from HBM
+// exactly once (the tiled kernel re-reads the weight tile once per 128-row M tile), the next tile's
+// loads are in flight during the MFMAs and the epilogue of the current one, and -- because one wave
+// holds a primal 16-row tile and the tangent tile of the same samples -- MFC_GEMM_LN16T can apply
+// the tangent of the fused LayerNorm in the same epilogue.
+// ---------------------------------------------------------------------------
+constexpr int NS_BN = 64, NS_K = 128, NS_KS = NS_K / 16, NS_LDR = 80, NS_MAXT = 4;
+struct NsPlan {
+    // per wave: up to 4 16-row tiles of C, processed in order; kind 0 = plain, 1 = LN16 primal,
+    // 2 = LN16 tangent of the entry before it
+    signed char tile[4][NS_MAXT];
+    signed char kind[4][NS_MAXT];
+};
+
+// raw buffer resources (base, num_records bytes): out-of-range lanes load 0 / drop their store in
+// hardware, so every VMEM instruction of the loop is unconditional and the compiler can count them
+// (s_waitcnt vmcnt(n) for the prefetched B tile instead of draining the epilogue stores too)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+constexpr uint32_t NS_OOB = 0xFFFFFF00u;
+
+template <int MT>
+__global__ void __launch_bounds__(GT)
+gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
+    typedef u16 T;
+    typedef Frag<T>::type frag_t;
+    __shared__ __attribute__((aligned(16))) T Bs[NS_K * NS_LDR];
+    __shared__ __attribute__((aligned(16))) float slab[4][16 * 68];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, r = lane & 15;
+    const T* A = (const T*)g.A;
+    const T* B = (const T*)g.B;
+    const int64_t N = g.N;
+
+    int mt[MT], kind[MT];
+    frag_t af[MT][NS_KS];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        mt[i] = plan.tile[wave][i];
+        kind[i] = plan.kind[wave][i];
+        const int64_t row = 16 * (int64_t)(mt[i] < 0 ? 0 : mt[i]) + r;
+#pragma unroll
+        for (int c = 0; c < NS_KS; ++c) {
+            if (mt[i] >= 0 && row < g.M) af[i][c] = *reinterpret_cast<const frag_t*>(A + row * g.lda + 16 * c + 4 * q);
+            else af[i][c] = frag_t{0, 0, 0, 0};
+        }
+    }
+
+    // land the A fragments here: left pending, their wait would sit at the first MFMA inside the loop and
+    // (vmcnt being one in-order counter) drain the previous iteration's stores every time round
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int c = 0; c < NS_KS; ++c) asm volatile("" ::"v"(af[i][c]));
+
+    // B tile staging: 128 rows x 8 chunks of 8 columns, 4 chunks per thread; byte offsets are tile-invariant
+    uint32_t boff[4], lds_off[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int ch = threadIdx.x + GT * p, k = ch >> 3, c8 = (ch & 7) * 8;
+        boff[p] = (uint32_t)((k * g.ldb + c8) * 2);
+        lds_off[p] = k * NS_LDR + c8;
+    }
+    u32x4 rb[4];
+    auto load_b = [&](int64_t tile) {
+        const int64_t n0 = tile * NS_BN;
+        // columns >= N of rows < K-1 alias the next row (finite weights, results never stored); the last row is clipped
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(B + n0, (uint32_t)(((NS_K - 1) * g.ldb + (N - n0)) * 2));
+#pragma unroll
+        for (int p = 0; p < 4; ++p) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[p], 0, 0);
+    };
+
+    float* cs = slab[wave];
+    const int lr = lane >> 2, lc = (lane & 3) * 16;
+    const bool has_alpha = g.alpha != 1.0f;
+    const __amdgpu_buffer_rsrc_t rs_bias = make_rsrc(g.bias, g.bias ? (uint32_t)(N * 4) : 0u);
+    // Loop shape: the B tile of iteration t+1 is requested at the top of iteration t and committed to LDS at its
+    // bottom, so the wait sits in the same iteration as the request and only has to skip the VMEM instructions
+    // issued in between (the epilogue stores) -- it never drains them.  The bias loads go first: vmcnt is in-order,
+    // waiting for anything younger than the B request would wait for the B tile as well.
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) {
+        load_b(tile);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs + lds_off[p]) = rb[p];
+    }
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int64_t col0 = tile * NS_BN + lc;
+        const bool colok = col0 < N;
+        float bias16[16];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_bias, colok ? (uint32_t)((col0 + 4 * k4) * 4) : NS_OOB, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t e = t[k];   // (bit_cast of a vector-element lvalue reads element 0 with this hipcc)
+                bias16[4 * k4 + k] = __builtin_bit_cast(float, e);
+            }
+        }
+        // prefetch (past the end: re-request this tile, never committed -- keeps the instruction unconditional)
+        {
+            const int64_t nt = tile + gridDim.x < ntiles ? tile + gridDim.x : tile;
+            load_b(nt);
+        }
+
+        f32x4 acc[MT][4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NS_KS; ++c) {
+            frag_t bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const T* bp = Bs + (16 * c + 4 * q + (r >> 2)) * NS_LDR + 16 * j + 4 * (r & 3);
+                bf[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(acc[i][j], af[i][c], bf[j]);
+        }
+        __syncthreads();   // B tile consumed: the next iteration may overwrite it while slower waves are in the epilogue
+
+        // epilogue: 16 rows at a time through the wave's slab, one lane = 16 consecutive columns of a row
+        float npr[16], rho_pr = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) npr[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cs[(4 * q + e) * 68 + 16 * j + r] = acc[i][j][e];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float v[16];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(cs + lr * 68 + lc + 4 * k4);
+                v[4 * k4] = t[0]; v[4 * k4 + 1] = t[1]; v[4 * k4 + 2] = t[2]; v[4 * k4 + 3] = t[3];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // wave-uniform geometry of this 16-row tile (a wave without an i-th tile gets an empty resource)
+            const int64_t row0 = 16 * (int64_t)(mt[i] < 0 ? 0 : mt[i]);
+            const int64_t rows_valid = mt[i] < 0 ? 0 : (g.M - row0 < 16 ? g.M - row0 : 16);
+            const int64_t rows_bias = g.bias_rows - row0;      // rows [0, rows_bias) of the tile take the bias
+            if (rows_bias >= 16) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] += bias16[k];
+            } else if (rows_bias > 0) {
+                const bool hb = lr < rows_bias;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] += hb ? bias16[k] : 0.f;
+            }
+            if (has_alpha) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] *= g.alpha;
+            }
+            if (kind[i] == 1) {
+                rho_pr = ln16_lane(v);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) npr[k] = v[k];
+            } else if (kind[i] == 2) {
+                ln16_tangent_lane(v, npr, rho_pr);
+            }
+            {   // 1/sigma of the LN16 primal rows (empty resource otherwise)
+                const uint32_t bytes = kind[i] == 1 ? (uint32_t)(rows_valid * (N >> 4) * 4) : 0u;
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(g.ln_rstd ? g.ln_rstd + row0 * (N >> 4) : nullptr, g.ln_rstd ? bytes : 0u);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, rho_pr), rs,
+                                                      colok ? (uint32_t)((lr * (N >> 4) + (col0 >> 4)) * 4) : NS_OOB, 0, 0);
+            }
+            const uint32_t cbytes = rows_valid > 0 ? (uint32_t)(((rows_valid - 1) * g.ldc + N) * 2) : 0u;
+            const uint32_t coff = colok ? (uint32_t)((lr * g.ldc + col0) * 2) : NS_OOB;
+            if (g.R) {
+                const uint32_t rbytes = rows_valid > 0 ? (uint32_t)(((rows_valid - 1) * g.ldr + N) * 2) : 0u;
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc((const T*)g.R + row0 * g.ldr, rbytes);
+                const uint32_t roff = colok ? (uint32_t)((lr * g.ldr + col0) * 2) : NS_OOB;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, roff + 16 * h, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[8 * h + 2 * k] += g.beta * __builtin_bit_cast(float, (uint32_t)(t[k] << 16));
+                        v[8 * h + 2 * k + 1] += g.beta * __builtin_bit_cast(float, (uint32_t)(t[k] & 0xffff0000u));
+                    }
+                }
+            }
+            const __amdgpu_buffer_rsrc_t rs_c = make_rsrc((T*)g.C + row0 * g.ldc, cbytes);
+            if (g.accum) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_c, coff + 16 * h, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[8 * h + 2 * k] += __builtin_bit_cast(float, (uint32_t)(t[k] << 16));
+                        v[8 * h + 2 * k + 1] += __builtin_bit_cast(float, (uint32_t)(t[k] & 0xffff0000u));
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32x4 t = {pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                                 pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+                __builtin_amdgcn_raw_buffer_store_b128(t, rs_c, coff + 16 * h, 0, 0);
+            }
+        }
+        // commit the prefetched B tile (every wave left the MFMA loop at the barrier above)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs + lds_off[p]) = rb[p];
+        __syncthreads();
+    }
+}
+
+// Build the per-wave tile plan.  Returns MT (1..4) or 0 when the shape does not fit.
+inline int ns_make_plan(int64_t M, int64_t bias_rows, bool ln, bool ln_tan, NsPlan& plan) {
+    for (int w = 0; w < 4; ++w)
+        for (int i = 0; i < NS_MAXT; ++i) { plan.tile[w][i] = -1; plan.kind[w][i] = 0; }
+    const int tiles = (int)ceil_div64(M, 16);
+    if (tiles > 16) return 0;
+    int cnt[4] = {0, 0, 0, 0};
+    auto put = [&](int w, int t, int kind) { plan.tile[w][cnt[w]] = (signed char)t; plan.kind[w][cnt[w]] = (signed char)kind; ++cnt[w]; };
+    auto emptiest = [&]() { int b = 0; for (int w = 1; w < 4; ++w) if (cnt[w] < cnt[b]) b = w; return b; };
+    if (!ln) {
+        for (int t = 0; t < tiles; ++t) { const int w = emptiest(); if (cnt[w] >= NS_MAXT) return 0; put(w, t, 0); }
+    } else {
+        if (bias_rows % 16 != 0 && bias_rows < M) return 0;      // tangent tiles must line up with primal tiles
+        const int ptiles = (int)ceil_div64(bias_rows < M ? bias_rows : M, 16);
+        const int ttiles = tiles - ptiles;
+        if (ttiles > ptiles) return 0;
+        for (int t = 0; t < ptiles; ++t) {
+            const int w = emptiest();
+            const bool pair = t < ttiles;
+            if (cnt[w] + (pair ? 2 : 1) > NS_MAXT) return 0;
+            put(w, t, 1);
+            if (pair) put(w, ptiles + t, ln_tan ? 2 : 0);
+        }
+    }
+    int mt = 0;
+    for (int w = 0; w < 4; ++w) mt = cnt[w] > mt ? cnt[w] : mt;
+    return mt;
+}
+
+// standalone tangent of the fused LayerNorm for shapes the N-streaming kernel does not take:
+// rows [bias_rows, M) of C hold the raw tangent, rows [0, M - bias_rows) the normalised primal
+template <typename T>
+__global__ void __launch_bounds__(256)
+ln16_tangent_kernel(int64_t rows, int64_t groups, T* C, int64_t ldc, int64_t bias_rows, const float* rstd) {
+    const int64_t total = rows * groups;
+    for (int64_t o = blockIdx.x * 256LL + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t row = o / groups, grp = o - row * groups;
+        float xd[16], n[16];
+        const T* pn = C + row * ldc + grp * 16;
+        T* pd = C + (bias_rows + row) * ldc + grp * 16;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { xd[k] = St<T>::ld(pd + k); n[k] = St<T>::ld(pn + k); }
+        ln16_tangent_lane(xd, n, rstd[row * groups + grp]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) St<T>::st(pd + k, xd[k]);
     }
 }
 
@@ -379,6 +675,17 @@ int launch(int flags, GemmArgs g, int bk, int splitk, int gelu, int64_t act_rows
     return rc;
 }
 
+// debugging / A-B switches (environment, read once): MFC_GEMM_NSTREAM=0 disables the N-streaming
+// kernel, MFC_GEMM_NS_BLOCKS caps its persistent grid (default 2 workgroups per CU)
+inline bool ns_disabled() {
+    static const bool off = [] { const char* e = getenv("MFC_GEMM_NSTREAM"); return e && e[0] == '0'; }();
+    return off;
+}
+inline int64_t ns_max_blocks() {
+    static const int64_t n = [] { const char* e = getenv("MFC_GEMM_NS_BLOCKS"); const long v = e ? atol(e) : 0; return (int64_t)(v > 0 ? v : 512); }();
+    return n;
+}
+
 }  // namespace
 
 extern "C" int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
@@ -424,9 +731,42 @@ extern "C" int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
         if (!g.vecC || use_ws) return MFC_ENOSYS;
         g.ln_rstd = ln_rstd;
     }
+    const bool ln = g.ln_rstd != nullptr, ln_tan = ln && (flags & MFC_GEMM_LN16T) && bias_rows < M;
+    if (ln_tan && M - bias_rows > bias_rows) return MFC_EINVAL;
+    g.m_base = 0;
+    // skinny NN products with the whole A operand in registers
+    if (dtype == MFC_BF16 && !ta && !tb && K == NS_K && !use_ws && g.vecA && g.vecB && g.vecC && !ns_disabled() &&
+        ldb < (1 << 23) && ldc < (1 << 26) && (!R || ldr < (1 << 26)) && N < (1LL << 29)) {   // 32-bit buffer offsets
+        NsPlan plan;
+        const int mt = ns_make_plan(M, bias_rows, ln, ln_tan, plan);
+        if (mt > 0) {
+            const int64_t ntiles = ceil_div64(N, NS_BN);
+            int64_t grid = ntiles < ns_max_blocks() ? ntiles : ns_max_blocks();
+            switch (mt) {
+                case 1: hipLaunchKernelGGL((gemm_nstream_kernel<1>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles); break;
+                case 2: hipLaunchKernelGGL((gemm_nstream_kernel<2>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles); break;
+                case 3: hipLaunchKernelGGL((gemm_nstream_kernel<3>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles); break;
+                default: hipLaunchKernelGGL((gemm_nstream_kernel<4>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles); break;
+            }
+            return mfc_launch_status();
+        }
+    }
     if (use_ws) {
         if (hipMemsetAsync(ws, 0, (size_t)M * N * sizeof(float), st) != hipSuccess) return MFC_EHIP;
     }
-    return dtype == MFC_F32 ? launch<float>(flags, g, bk, splitk, gelu, act_rows, st)
-                            : launch<u16>(flags, g, bk, splitk, gelu, act_rows, st);
+    int rc = dtype == MFC_F32 ? launch<float>(flags, g, bk, splitk, gelu, act_rows, st)
+                              : launch<u16>(flags, g, bk, splitk, gelu, act_rows, st);
+    if (!rc && ln_tan) {
+        const int64_t rows = M - bias_rows, groups = N >> 4;
+        int64_t blocks = ceil_div64(rows * groups, 256);
+        if (blocks > 8192) blocks = 8192;
+        if (dtype == MFC_F32)
+            hipLaunchKernelGGL((ln16_tangent_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, rows, groups,
+                               (float*)C, ldc, bias_rows, (const float*)ln_rstd);
+        else
+            hipLaunchKernelGGL((ln16_tangent_kernel<u16>), dim3((unsigned)blocks), dim3(256), 0, st, rows, groups,
+                               (u16*)C, ldc, bias_rows, (const float*)ln_rstd);
+        rc = mfc_launch_status();
+    }
+    return rc;
 }

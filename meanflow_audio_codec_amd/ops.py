@@ -4,12 +4,12 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import GEMM_ACCUM, GEMM_GELU, GEMM_LN16, GEMM_TRANS_A, GEMM_TRANS_B  # noqa: F401
+from ._lib import GEMM_ACCUM, GEMM_GELU, GEMM_LN16, GEMM_LN16T, GEMM_TRANS_A, GEMM_TRANS_B  # noqa: F401
 
 
 def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a=False, trans_b=False, bias=None, bias_rows=None,
          gelu=False, act_rows=None, alpha=1.0, residual=None, beta=1.0, out=None, accumulate=False,
-         splitk=1, ws=None, ln_rstd=None) -> torch.Tensor:
+         splitk=1, ws=None, ln_rstd=None, ln_tangent=False) -> torch.Tensor:
     """C = alpha*(op(A) op(B) + bias) + beta*residual through ``mfc_gemm``.
 
     A: [M,K] (or [K,M] if trans_a), B: [K,N] (or [N,K] if trans_b); 2-D, last
@@ -25,7 +25,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a=False, trans_b=False, bias
         out = torch.empty((M, N), dtype=A.dtype, device=A.device)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == A.dtype
     flags = (GEMM_TRANS_A if trans_a else 0) | (GEMM_TRANS_B if trans_b else 0) \
-        | (GEMM_ACCUM if accumulate else 0) | (GEMM_GELU if gelu else 0) | (GEMM_LN16 if ln_rstd is not None else 0)
+        | (GEMM_ACCUM if accumulate else 0) | (GEMM_GELU if gelu else 0) | (GEMM_LN16 if ln_rstd is not None else 0) \
+        | (GEMM_LN16T if (ln_rstd is not None and ln_tangent) else 0)
     if ln_rstd is not None:
         assert ln_rstd.dtype == torch.float32 and ln_rstd.is_contiguous() and N % 16 == 0
         assert ln_rstd.numel() >= (M if bias_rows is None else bias_rows) * (N // 16)

@@ -104,3 +104,59 @@ def test_gemm_ln16_epilogue(dtype, tol):
     assert (C.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
     assert ((rho.double() - torch.rsqrt(var + 1e-6).reshape(R, -1)).abs().max() /
             torch.rsqrt(var + 1e-6).max()).item() < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+NS_SHAPES = [(192, 1040), (64, 64), (256, 3200), (250, 328), (16, 16), (130, 72)]
+
+
+@pytest.mark.parametrize("M,N", NS_SHAPES)
+def test_gemm_nstream_shapes(M, N):
+    """bf16 NN products with K = 128 and M <= 256 take the N-streaming kernel (A in registers):
+    bias on the first rows, alpha, residual, accumulate -- against fp64."""
+    from meanflow_audio_codec_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    dtype, K = torch.bfloat16, 128
+    A = torch.randn(M, K, generator=g, device="cuda").to(dtype)
+    B = torch.randn(K, N, generator=g, device="cuda").to(dtype)
+    bias = torch.randn(N, generator=g, device="cuda")
+    R = torch.randn(M, N, generator=g, device="cuda").to(dtype)
+    br = max(1, (2 * M) // 3)
+    ref = _ref(A, B, False, False, bias, br, 0.5, R, -1.5)
+    C = ops.gemm(A, B, bias=bias, bias_rows=br, alpha=0.5, residual=R, beta=-1.5)
+    assert (C.double() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    C0 = torch.randn(M, N, generator=g, device="cuda").to(dtype)
+    C1 = ops.gemm(A, B, out=C0.clone(), accumulate=True)
+    ref1 = A.double() @ B.double() + C0.double()
+    assert (C1.double() - ref1).abs().max().item() <= 2e-2 * max(1.0, ref1.abs().max().item())
+
+
+def _ln_ref(pre, R, N):
+    grp = pre[:R].reshape(R, N // 16, 16)
+    mu, var = grp.mean(-1, keepdim=True), grp.var(-1, unbiased=False, keepdim=True)
+    rho = torch.rsqrt(var + 1e-6)
+    return (grp - mu) * rho, rho
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("R,nt,N", [(32, 16, 16 * 37), (128, 64, 16 * 40), (48, 48, 16 * 9), (20, 7, 16 * 5)])
+def test_gemm_ln16_tangent_rows(dtype, tol, R, nt, N):
+    """MFC_GEMM_LN16 | MFC_GEMM_LN16T: primal rows LayerNorm'd, tangent rows (R + j <-> j) get the tangent of
+    that LayerNorm.  (bf16 with 16-aligned R: fused in the N-streaming kernel; otherwise a second kernel.)"""
+    from meanflow_audio_codec_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    K = 128
+    X = torch.randn(R + nt, K, generator=g, device="cuda").to(dtype)
+    W = (torch.randn(K, N, generator=g, device="cuda") / 8).to(dtype)
+    b = torch.randn(N, generator=g, device="cuda")
+    rho = torch.zeros(R, N // 16, device="cuda")
+    C = ops.gemm(X, W, bias=b, bias_rows=R, ln_rstd=rho, ln_tangent=True)
+    pre = X.double() @ W.double()
+    pre[:R] += b.double()
+    n, rr = _ln_ref(pre, R, N)
+    xd = pre[R:].reshape(nt, N // 16, 16)
+    xc = xd - xd.mean(-1, keepdim=True)
+    nd = rr[:nt] * (xc - n[:nt] * (n[:nt] * xc).mean(-1, keepdim=True))
+    ref = torch.cat([n.reshape(R, N), nd.reshape(nt, N)], 0)
+    assert (C[:R].double() - ref[:R]).abs().max().item() <= tol * max(1.0, ref[:R].abs().max().item())
+    assert (C[R:].double() - ref[R:]).abs().max().item() <= tol * max(1.0, ref[R:].abs().max().item())
+    assert ((rho.double() - rr.reshape(R, -1)).abs().max() / rr.max()).item() < (1e-4 if dtype == torch.float32 else 2e-2)
