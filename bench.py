@@ -82,10 +82,10 @@ def algorithmic_work(name, ints, nn):
         px = R * s * s
         conv, exp, con = 2 * 9 * 16 * 16, 2 * 16 * 32, 2 * 32 * 16
         if name == "mfc_cnx_stats":
-            j = 2 if nn[2] else 1
+            j = 2 if nn[1] else 1
             return es * px * 16 * j, float(px) * (conv + exp) * j, dt
         if name == "mfc_cnx_apply":
-            j = 2 if nn[2] else 1
+            j = 2 if nn[1] else 1
             return es * px * 16 * 2 * j, float(px) * (conv + exp + con) * j, dt
         if name == "mfc_cnx_bwd_stats":
             return es * px * 16 * 2, float(px) * (conv + exp + con), dt
@@ -119,7 +119,7 @@ def symbol_of(name, ints, nn):
     if name.startswith("mfc_cnx_"):
         T = "float" if ints[0] == 0 else "unsigned short"
         if name in ("mfc_cnx_stats", "mfc_cnx_apply"):
-            return f"cnx_fwd_kernel<{T}, {'true' if nn[2] else 'false'}, {0 if name == 'mfc_cnx_stats' else 1}>"
+            return f"cnx_fwd_kernel<{T}, {'true' if nn[1] else 'false'}, {0 if name == 'mfc_cnx_stats' else 1}>"
         if name == "mfc_cnx_bwd_stats":
             return f"cnx_bwd_kernel<{T}, 0>"
         if name == "mfc_cnx_bwd_main":

@@ -110,9 +110,10 @@ int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
 /* The spatial part of ConditionalConvNeXtBlock, between input_proj2 and
  * output_proj1, on NHWC maps h0 [R, s, s, 16] (R = rows of the row-stacked
  * batch; channel count C = min(16, cond/4) = 16 for every shipped config,
- * other C -> MFC_ENOSYS).  The kernels take h1 = LN_C(h0) (produced by mfc_gemm's MFC_GEMM_LN16
- * epilogue or mfc_ln16_fwd) and rho0 = 1/sqrt(var+eps) per pixel [R, s*s] fp32 (needed only together
- * with a tangent h0dot -- the RAW tangent of h0 -- and by mfc_cnx_bwd_conv):
+ * other C -> MFC_ENOSYS).  The kernels take h1 = LN_C(h0) and, for a tangent, h1dot = the tangent of
+ * that LayerNorm (both produced by mfc_gemm's MFC_GEMM_LN16 / MFC_GEMM_LN16T epilogue, or by
+ * mfc_ln16_fwd / mfc_ln16_jvp); rho0 = 1/sqrt(var+eps) per pixel [R, s*s] fp32 is only needed by
+ * mfc_cnx_bwd_conv.  s <= 8000.
  *   h2 = (1+scale) * LN_C(h0) + shift                 conv_flow.py:181-186
  *   c1 = Conv3x3_SAME(h2) ; n1 = LN_C(c1)             conv_flow.py:74-84
  *   g1 = gelu(Conv1x1_{16->32}(n1))                   conv_flow.py:87-88
@@ -141,10 +142,10 @@ typedef struct {
     float* grn_gamma; float* grn_beta; float* con_w; float* con_b; float* ls;
 } mfc_cnx_grads;
 
-/* pass 1: S1[r,ch] += sum_hw g1^2 ; S2[r,ch] += sum_hw g1*g1dot (if h0dot).
+/* pass 1: S1[r,ch] += sum_hw g1^2 ; S2[r,ch] += sum_hw g1*g1dot (if h1dot).
  * scale/shift (and their tangents) are fp32 [R,16]; S1/S2 fp32 [R,32] must be
  * zeroed by the caller. */
-int mfc_cnx_stats(int dtype, int64_t R, int s, const void* h1, const float* rho0, const void* h0dot,
+int mfc_cnx_stats(int dtype, int64_t R, int s, const void* h1, const void* h1dot,
                   const float* scale, const float* shift, const float* scaledot, const float* shiftdot,
                   const mfc_cnx_params* p, float* S1, float* S2, void* stream);
 
@@ -154,7 +155,7 @@ int mfc_grn_finalize(int64_t R, const float* S1, const float* S2, float* G, floa
                      void* stream);
 
 /* pass 2: o (and odot) [R,s,s,16] dtype. */
-int mfc_cnx_apply(int dtype, int64_t R, int s, const void* h1, const float* rho0, const void* h0dot,
+int mfc_cnx_apply(int dtype, int64_t R, int s, const void* h1, const void* h1dot,
                   const float* scale, const float* shift, const float* scaledot, const float* shiftdot,
                   const mfc_cnx_params* p, const float* q, const float* qdot,
                   void* o, void* odot, void* stream);
@@ -183,6 +184,11 @@ int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h1, const float* r
  * y = LN_16(x) [n_pixels,16] dtype, rstd[n_pixels] fp32 (may be NULL).  The hot path fuses this into the
  * producing product (mfc_gemm flag MFC_GEMM_LN16); this entry point is the standalone form. */
 int mfc_ln16_fwd(int dtype, int64_t n_pixels, const void* x, void* y, float* rstd, void* stream);
+
+/* Tangent of that LayerNorm (what MFC_GEMM_LN16T fuses): n = LN_16(x), rstd from mfc_ln16_fwd, xdot the raw
+ * tangent of x; ndot = rstd * (xd - n * mean(n * xd)) with xd = xdot - mean(xdot).  ndot may alias xdot. */
+int mfc_ln16_jvp(int dtype, int64_t n_pixels, const void* n, const float* rstd, const void* xdot, void* ndot,
+                 void* stream);
 
 /* ------------------------------------------------------------------ */
 /* Loss-step element-wise kernels                                      */

@@ -50,7 +50,7 @@ def build(force: bool = False, verbose: bool = True, jobs: int = 4) -> pathlib.P
     def cc(job):
         src, obj = job
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", str(src), "-o", str(obj),
-               "-Wall", "-Wno-unused-function", "-munsafe-fp-atomics",
+               "-Wall", "-Wno-unused-function", "-munsafe-fp-atomics", "-Wno-inline-asm",
                "-mllvm", "-amdgpu-mfma-vgpr-form=1"]   # MFMA results straight into VGPRs (no v_accvgpr_read traffic)
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -42,9 +42,10 @@ SIGNATURES = {
     "mfc_gemm": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64,
                          _P, c_int64, c_int64, c_float, _P, c_int64, c_float, c_int, _P, _P, _P]),
     "mfc_ln16_fwd": (c_int, [c_int, c_int64, _P, _P, _P, _P]),
-    "mfc_cnx_stats": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_ln16_jvp": (c_int, [c_int, c_int64, _P, _P, _P, _P, _P]),
+    "mfc_cnx_stats": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_grn_finalize": (c_int, [c_int64, _P, _P, _P, _P, _P, _P]),
-    "mfc_cnx_apply": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_cnx_apply": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_cnx_bwd_stats": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_grn_bwd_finalize": (c_int, [c_int64, _P, _P, _P, _P, _P]),
     "mfc_cnx_bwd_main": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

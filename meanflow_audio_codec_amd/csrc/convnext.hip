@@ -50,6 +50,11 @@ struct DevG {
 };
 
 __device__ inline void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// make a just-loaded value land HERE: left pending, the compiler's wait for it would sit at its first use in
+// the tile loop's common path and (vmcnt being one in-order counter) drain the halo DMA on every tile
+__device__ inline void land(const float& v) { asm volatile("" ::"v"(v)); }
+__device__ inline void land(const f32x4& v) { asm volatile("" ::"v"(v)); }
+__device__ inline void land(const s16x4& v) { asm volatile("" ::"v"(v)); }
 
 // sum over the 4 lanes sharing (lane & 15): lanes 16 and 32 apart.  gfx950's
 // v_permlane16_swap / v_permlane32_swap exchange 16-lane rows / 32-lane halves
@@ -302,16 +307,130 @@ __device__ inline TileCoord tile_next(const Geo& g, TileCoord c) {
     return c;
 }
 
-// Per-lane weights / constants of the forward chain.  Lane (q, m): m = pixel
-// within the tile row, channel constants are those of channels 4q..4q+3.
+// ---------------------------------------------------------------------------
+// Halo tiles by LDS-DMA.  The FiLM modulation h2 = (1+scale) h1 + shift is folded into the conv weights
+// per row r (W' = diag(1+scale) Wc, bias' = bc + sum_taps Wc^T shift; border tiles mask the taps that
+// fall outside the image), so a halo tile is a verbatim copy of h1 (and of its tangent) and goes
+// global -> LDS with global_load_lds_dwordx4: no staging registers, no VALU, double-buffered so the
+// request for tile t+1 is in flight during all of tile t.
+// ---------------------------------------------------------------------------
+__device__ uint4 g_zero16;   // 16 zero bytes: DMA source of halo pixels outside the image
+
+typedef __attribute__((address_space(1))) void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t BUF_OOB = 0xFFFFFF00u;   // offset no buffer resource covers: load 0 / store dropped
+
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+// 4 consecutive channels through a buffer resource (unconditional instructions: see the vmcnt note below)
+__device__ inline void buf_st4(__amdgpu_buffer_rsrc_t rs, uint32_t off, const float v[4], const float*) {
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1]),
+                                                 __builtin_bit_cast(uint32_t, v[2]), __builtin_bit_cast(uint32_t, v[3])},
+                                           rs, off, 0, 0);
+}
+__device__ inline void buf_st4(__amdgpu_buffer_rsrc_t rs, uint32_t off, const float v[4], const u16*) {
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, rs, off, 0, 0);
+}
+__device__ inline f32x4 buf_ld_frag(__amdgpu_buffer_rsrc_t rs, uint32_t off, const float*) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+}
+__device__ inline s16x4 buf_ld_frag(__amdgpu_buffer_rsrc_t rs, uint32_t off, const u16*) {
+    return __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+}
+
+template <typename T> struct Halo {
+    static constexpr int EPC = 16 / sizeof(T);          // elements per 16-byte chunk
+    static constexpr int CPP = 16 / EPC;                // chunks per pixel
+    static constexpr int CHUNKS = NHALO * CPP;
+    static constexpr int NI = (CHUNKS + NT - 1) / NT;   // DMA instructions per wave
+    static constexpr int ELEMS = NHALO * 16;
+    // LDS layout [HH][CPP][HW] of 16-byte chunks (chunk c of the HW pixels of a halo row are contiguous): the
+    // chain reads channels 4q..4q+3 of 16 consecutive pixels, which then sit in 16 consecutive chunks -- no bank
+    // conflicts.  (Pixel-major [HH][HW][CPP] would put pixels m and m+8 on the same banks.)
+    __device__ static inline int off(int hy, int hx, int q) {
+        const int c = (4 * q) / EPC, w = (4 * q) % EPC;
+        return ((hy * CPP + c) * HW + hx) * EPC + w;
+    }
+    int hyx[NI];   // (hy << 8) | hx of this lane's chunk in instruction i, -1 past the end of the tile
+    int rel[NI];   // element offset of that chunk relative to the tile's origin pixel (y0, x0)
+    __device__ inline void init(int s, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int ch = (i * NWAVES + wave) * 64 + lane;     // = LDS chunk slot
+            const int hy = ch / (CPP * HW), rem = ch - hy * (CPP * HW);
+            const int part = rem / HW, hx = rem - part * HW;
+            hyx[i] = ch < CHUNKS ? ((hy << 8) | hx) : -1;
+            rel[i] = ((hy - 1) * s + (hx - 1)) * 16 + part * EPC;
+        }
+    }
+    // request the halo of tile (y0, x0) of the [s, s, 16] image `img` into the LDS tile at byte address `dst`
+    __device__ inline void request(uint32_t dst, const T* img, int s, int y0, int x0, int wave) const {
+        const int64_t org = ((int64_t)y0 * s + x0) * 16;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (hyx[i] >= 0) {
+                const int gy = y0 + (hyx[i] >> 8) - 1, gx = x0 + (hyx[i] & 255) - 1;
+                const bool in = (unsigned)gy < (unsigned)s && (unsigned)gx < (unsigned)s;
+                const T* gp = in ? img + org + rel[i] : reinterpret_cast<const T*>(&g_zero16);
+                // Inline asm, not __builtin_amdgcn_global_load_lds: the compiler cannot tell the two LDS buffers
+                // apart and would drain vmcnt before every LDS read of the tile being computed.  (Hiding a VMEM
+                // instruction from its in-order vmcnt model only makes the waits it inserts stricter.)
+                const uint32_t lds_addr = dst + (i * NWAVES + wave) * 1024;   // 64 lanes x 16 bytes per instruction
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                             :: "v"(gp), "s"(lds_addr) : "memory", "m0");
+            }
+        }
+    }
+};
+
+// vmcnt note.  vmcnt is one in-order counter over loads, stores and LDS-DMA.  The DMA for tile t+1 is
+// requested at the top of tile t and awaited at its bottom with s_waitcnt vmcnt(S), S = the number of
+// VMEM instructions this wave issues in between.  For S to be a compile-time constant those
+// instructions are buffer loads / stores whose out-of-image lanes are steered to BUF_OOB instead of
+// being branched around, and __builtin_amdgcn_sched_barrier pins them on their side of the request.
+
+template <typename T> struct Lds2 {
+    T* tile0;      // double-buffered halo of h1: buffer b at tile0 + b * Halo<T>::ELEMS
+    T* tiled0;     // ... of its tangent (forward JVP)
+    uint32_t tile0_addr, tiled0_addr;   // their LDS byte addresses (M0 of the DMA)
+    T* wc0;        // [9][64 lanes][4]: the unscaled conv weights as A-operand fragments
+    T* ws;         // per wave [6][16][CS] weight-gradient transpose scratch (backward main)
+    float* fsc;    // [4][16] scale, shift, scaledot, shiftdot of the current row r
+};
+template <typename T>
+__host__ __device__ inline size_t lds2_bytes(bool jvp, bool ws) {
+    size_t b = (size_t)Halo<T>::ELEMS * sizeof(T) * 2 * (jvp ? 2 : 1) + (size_t)9 * 64 * 4 * sizeof(T);
+    if (ws) b += (size_t)NWAVES * WS_TILES * 16 * CS * sizeof(T);
+    b = (b + 15) & ~(size_t)15;
+    return b + 64 * sizeof(float);
+}
+template <typename T>
+__device__ inline Lds2<T> carve2(unsigned char* base, bool jvp, bool ws, int wave) {
+    Lds2<T> l;
+    T* p = (T*)base;
+    const uint32_t base_addr = (uint32_t)(uintptr_t)(lvoid_t*)base;
+    l.tile0 = p; l.tile0_addr = base_addr; p += 2 * Halo<T>::ELEMS;
+    l.tiled0 = p; l.tiled0_addr = base_addr + 2 * Halo<T>::ELEMS * (uint32_t)sizeof(T);
+    if (jvp) p += 2 * Halo<T>::ELEMS;
+    l.wc0 = p; p += 9 * 64 * 4;
+    l.ws = p + (size_t)wave * WS_TILES * 16 * CS;
+    size_t b = (size_t)Halo<T>::ELEMS * sizeof(T) * 2 * (jvp ? 2 : 1) + (size_t)9 * 64 * 4 * sizeof(T);
+    if (ws) b += (size_t)NWAVES * WS_TILES * 16 * CS * sizeof(T);
+    b = (b + 15) & ~(size_t)15;
+    l.fsc = (float*)(base + b);
+    return l;
+}
+
+// Per-lane weights / constants of the forward chain that do not depend on the row r.  Lane (q, m):
+// m = pixel within the tile row, channel constants are those of channels 4q..4q+3.
 template <typename T> struct FwdW {
     typedef typename Frag<T>::type frag_t;
-    frag_t wc[9], we[2], wp[2];
+    frag_t we[2], wp[2];
     float bc[4], be[2][4], bp[4], ls[4], gam[2][4], bet[2][4];
     __device__ inline void load(const Dev& d, int q, int m) {
-        const T* cw = (const T*)d.conv_w;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wc[t] = load_bfrag<T>(cw + t * 256, 16, 1, 0, 0, q, m);
         const T* ew = (const T*)d.exp_w;  // [16][32]
         we[0] = load_bfrag<T>(ew, 32, 1, 0, 0, q, m);
         we[1] = load_bfrag<T>(ew, 32, 1, 0, 16, q, m);
@@ -328,6 +447,61 @@ template <typename T> struct FwdW {
                 bet[j][i] = d.beta[16 * j + 4 * q + i];
             }
         }
+        // see land(): every one of these is first used inside the tile loop
+        land(we[0]); land(we[1]); land(wp[0]); land(wp[1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            land(bc[i]); land(bp[i]); land(ls[i]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { land(be[j][i]); land(gam[j][i]); land(bet[j][i]); }
+        }
+    }
+};
+// conv weights [tap][ic][oc] as A-operand fragments of the transposed product (row = oc, k = ic), one per lane
+template <typename T>
+__device__ inline void stash_conv_w(T* wc0, const Dev& d, int q, int m, int lane) {
+    typedef typename Frag<T>::type frag_t;
+    const T* cw = (const T*)d.conv_w;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        *reinterpret_cast<frag_t*>(wc0 + (t * 64 + lane) * 4) = load_bfrag<T>(cw + t * 256, 16, 1, 0, 0, q, m);
+}
+
+// The row-r dependent part: FiLM folded into the conv.
+template <typename T, bool JVP> struct RowW {
+    typedef typename Frag<T>::type frag_t;
+    frag_t wc[9];               // diag(1 + scale) Wc
+    frag_t wcd[JVP ? 9 : 1];    // diag(scaledot) Wc
+    f32x4 b, bd;                // bc + sum_taps Wc^T shift (interior tiles) and its tangent
+    frag_t shf, shdf;           // shift / shiftdot as a B operand (border tiles mask it per tap)
+    float sc1[4], sh[4];        // 1 + scale, shift of channels 4q..4q+3 (FiLM of the centre pixel)
+    __device__ inline void set(const T* wc0, const float bc[4], const float* sc, const float* shp, const float* scd,
+                               const float* shd, int64_t r, int q, int lane) {
+        float scd4[4] = {0.f, 0.f, 0.f, 0.f}, shd4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sc1[i] = 1.0f + sc[r * 16 + 4 * q + i];
+            sh[i] = shp[r * 16 + 4 * q + i];
+            if constexpr (JVP) { scd4[i] = scd[r * 16 + 4 * q + i]; shd4[i] = shd[r * 16 + 4 * q + i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { land(sc1[i]); land(sh[i]); }
+        make_frag(shf, sh[0], sh[1], sh[2], sh[3]);
+        make_frag(shdf, shd4[0], shd4[1], shd4[2], shd4[3]);
+        b = f32x4{bc[0], bc[1], bc[2], bc[3]};
+        bd = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const frag_t w0 = *reinterpret_cast<const frag_t*>(wc0 + (t * 64 + lane) * 4);
+            float wv[4];
+            unfrag(w0, wv);
+            make_frag(wc[t], wv[0] * sc1[0], wv[1] * sc1[1], wv[2] * sc1[2], wv[3] * sc1[3]);
+            mma16(b, w0, shf);
+            if constexpr (JVP) {
+                make_frag(wcd[t], wv[0] * scd4[0], wv[1] * scd4[1], wv[2] * scd4[2], wv[3] * scd4[3]);
+                mma16(bd, w0, shdf);
+            }
+        }
     }
 };
 
@@ -341,21 +515,39 @@ template <typename T, bool JVP> struct RowFwd {
     f32x4 g[2], gp[2], gd[2];   // gelu(e), gelu'(e) (when WG), tangent of g (when JVP)
 };
 
+// tile / tiled: dense halo of h1 / its tangent.  border: the tile touches the image edge (uniform).
 template <typename T, bool JVP, bool WG>
-__device__ inline void chain_row(const Lds<T>& l, const FwdW<T>& w, int y, int q, int m, RowFwd<T, JVP>& o) {
+__device__ inline void chain_row(const T* tile, const T* tiled, const T* wc0, const FwdW<T>& w, const RowW<T, JVP>& rw,
+                                 bool border, int gy, int gx, int s, int y, int q, int m, int lane, RowFwd<T, JVP>& o) {
     typedef typename Frag<T>::type frag_t;
-    f32x4 acc = f32x4{w.bc[0], w.bc[1], w.bc[2], w.bc[3]};
-    f32x4 accd = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = rw.b, accd = rw.bd;
+    if (border) {
+        // zero padding applies to h2, not h1: only the taps inside the image carry the shift
+        acc = f32x4{w.bc[0], w.bc[1], w.bc[2], w.bc[3]};
+        accd = f32x4{0.f, 0.f, 0.f, 0.f};
+        frag_t z;
+        make_frag(z, 0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const bool in = (unsigned)(gy + dy - 1) < (unsigned)s && (unsigned)(gx + dx - 1) < (unsigned)s;
+                const frag_t w0 = *reinterpret_cast<const frag_t*>(wc0 + ((dy * 3 + dx) * 64 + lane) * 4);
+                mma16(acc, w0, in ? rw.shf : z);
+                if constexpr (JVP) mma16(accd, w0, in ? rw.shdf : z);
+            }
+    }
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-            const int off = ((y + dy) * HW + (m + dx)) * CS + 4 * q;
-            const frag_t a = *reinterpret_cast<const frag_t*>(l.h2s + off);
-            mma16(acc, w.wc[dy * 3 + dx], a);      // c1^T = Wc^T h2^T
+            const int off = Halo<T>::off(y + dy, m + dx, q);
+            const frag_t a = *reinterpret_cast<const frag_t*>(tile + off);
+            mma16(acc, rw.wc[dy * 3 + dx], a);      // c1^T = W'^T h1^T
             if constexpr (JVP) {
-                const frag_t ad = *reinterpret_cast<const frag_t*>(l.aux + off);
-                mma16(accd, w.wc[dy * 3 + dx], ad);
+                const frag_t ad = *reinterpret_cast<const frag_t*>(tiled + off);
+                mma16(accd, rw.wc[dy * 3 + dx], ad);
+                mma16(accd, rw.wcd[dy * 3 + dx], a);
             }
         }
     float v[4] = {acc[0], acc[1], acc[2], acc[3]}, mean;
@@ -386,27 +578,28 @@ __device__ inline void chain_row(const Lds<T>& l, const FwdW<T>& w, int y, int q
 
 struct FwdArgs {
     Geo geo;
-    const void* h0; const void* h0d; const float* rho;
+    const void* h0; const void* h0d;
     const float* sc; const float* sh; const float* scd; const float* shd;
     Dev p;
     float* S1; float* S2;          // stats mode
     const float* q; const float* qd;  // apply mode
     void* o; void* od;
-    int dbg;   // profiling ablations only (env MFC_CNX_DBG): 1 = skip the MFMA chain, 2 = stage only the first tile
+    int dbg;   // profiling ablations (env MFC_CNX_DBG): 1 = skip the row chain, 2 = request only the first tile
 };
 
 template <typename T, bool JVP>
-__device__ inline void load_film(const Lds<T>& l, const float* sc, const float* sh, const float* scd,
+__device__ inline void load_film(float* fsc, const float* sc, const float* sh, const float* scd,
                                  const float* shd, int64_t r) {
     if (threadIdx.x < 16) {
-        l.fsc[threadIdx.x] = sc[r * 16 + threadIdx.x];
-        l.fsc[16 + threadIdx.x] = sh[r * 16 + threadIdx.x];
+        fsc[threadIdx.x] = sc[r * 16 + threadIdx.x];
+        fsc[16 + threadIdx.x] = sh[r * 16 + threadIdx.x];
         if constexpr (JVP) {
-            l.fsc[32 + threadIdx.x] = scd[r * 16 + threadIdx.x];
-            l.fsc[48 + threadIdx.x] = shd[r * 16 + threadIdx.x];
+            fsc[32 + threadIdx.x] = scd[r * 16 + threadIdx.x];
+            fsc[48 + threadIdx.x] = shd[r * 16 + threadIdx.x];
         }
     }
 }
+__device__ inline bool tile_on_border(int s, int y0, int x0) { return y0 == 0 || x0 == 0 || y0 + TH >= s || x0 + TW >= s; }
 
 // MODE 0: GRN statistics; MODE 1: apply GRN, contract, layer-scale, residual.
 template <typename T, bool JVP, int MODE>
@@ -414,20 +607,28 @@ __global__ void __launch_bounds__(NT)
 cnx_fwd_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Frag<T>::type frag_t;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, m = lane & 15;
-    Lds<T> l = carve<T>(smem, JVP, false, wave);
+    Lds2<T> l = carve2<T>(smem, JVP, false, wave);
     FwdW<T> w;
     w.load(a.p, q, m);
+    if (wave == 0) stash_conv_w<T>(l.wc0, a.p, q, m, lane);
     const int s = a.geo.s;
+    const int64_t img = (int64_t)s * s * 16;
     const T* h0 = (const T*)a.h0;
     const T* h0d = (const T*)a.h0d;
+    Halo<T> hl;
+    hl.init(s, wave, lane);
+    RowW<T, JVP> rw;
+    constexpr int S_VMEM = MODE == 1 ? RPW * (JVP ? 2 : 1) : 0;   // stores between a DMA request and its wait
 
     int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
     int64_t t1 = t0 + a.geo.chunk < a.geo.total ? t0 + a.geo.chunk : a.geo.total;
     int64_t rcur = -1;
     float s1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, s2[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float qv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, qdv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    __amdgpu_buffer_rsrc_t rs_o = make_rsrc(nullptr, 0), rs_od = make_rsrc(nullptr, 0);
 
     auto flush_stats = [&](int64_t r) {
         if constexpr (MODE == 0) {
@@ -446,19 +647,23 @@ cnx_fwd_kernel(FwdArgs a) {
         }
     };
 
-    HaloRaw<T, JVP> raw;
     TileCoord tnext = tile_coord(a.geo, t0 < t1 ? t0 : 0);
-    if (t0 < t1) halo_load<T, JVP>(raw, h0, h0d, a.rho, tnext.r, s, tnext.y0, tnext.x0);
+    if (t0 < t1) {
+        hl.request(l.tile0_addr, h0 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
+        if constexpr (JVP) hl.request(l.tiled0_addr, h0d + tnext.r * img, s, tnext.y0, tnext.x0, wave);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int64_t t = t0; t < t1; ++t) {
         const TileCoord tc = tnext;
         tnext = tile_next(a.geo, tc);
         const int64_t r = tc.r;
         const int y0 = tc.y0, x0 = tc.x0;
-        __syncthreads();  // previous tile fully consumed
+        const int cur = (int)((t - t0) & 1);
+        __syncthreads();  // every wave's share of tile t has landed (each waited for its own); tile t-1 fully consumed
         if (r != rcur) {
             if (rcur >= 0) flush_stats(rcur);
             rcur = r;
-            load_film<T, JVP>(l, a.sc, a.sh, a.scd, a.shd, r);
+            rw.set(l.wc0, w.bc, a.sc, a.sh, a.scd, a.shd, r, q, lane);
             if constexpr (MODE == 1) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -467,12 +672,28 @@ cnx_fwd_kernel(FwdArgs a) {
                         qv[j][i] = a.q[r * 32 + 16 * j + 4 * q + i];
                         if constexpr (JVP) qdv[j][i] = a.qd[r * 32 + 16 * j + 4 * q + i];
                     }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { land(qv[j][i]); if constexpr (JVP) land(qdv[j][i]); }
+                rs_o = make_rsrc((const T*)a.o + r * img, (uint32_t)(img * sizeof(T)));
+                if constexpr (JVP) {
+                    rs_od = make_rsrc((const T*)a.od + r * img, (uint32_t)(img * sizeof(T)));
+                    load_film<T, true>(l.fsc, a.sc, a.sh, a.scd, a.shd, r);
+                    __syncthreads();
+                }
             }
-            __syncthreads();
         }
-        if (!(a.dbg & 2) || t == t0) halo_commit<T, JVP>(l, raw);
-        __syncthreads();
-        if (t + 1 < t1 && !(a.dbg & 2)) halo_load<T, JVP>(raw, h0, h0d, a.rho, tnext.r, s, tnext.y0, tnext.x0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < t1 && !(a.dbg & 2)) {
+            constexpr uint32_t TB = Halo<T>::ELEMS * sizeof(T);
+            hl.request(l.tile0_addr + (cur ^ 1) * TB, h0 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
+            if constexpr (JVP) hl.request(l.tiled0_addr + (cur ^ 1) * TB, h0d + tnext.r * img, s, tnext.y0, tnext.x0, wave);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const T* tile = l.tile0 + cur * Halo<T>::ELEMS;
+        const T* tiled = l.tiled0 + cur * Halo<T>::ELEMS;
+        const bool border = tile_on_border(s, y0, x0);
         const int gx = x0 + m;
 #pragma unroll 1
         for (int ri = 0; ri < ((a.dbg & 1) ? 0 : RPW); ++ri) {
@@ -480,7 +701,7 @@ cnx_fwd_kernel(FwdArgs a) {
             const int gy = y0 + y;
             const bool ok = gy < s && gx < s;
             RowFwd<T, JVP> f;
-            chain_row<T, JVP, false>(l, w, y, q, m, f);
+            chain_row<T, JVP, false>(tile, tiled, l.wc0, w, rw, border, gy, gx, s, y, q, m, lane, f);
             if constexpr (MODE == 0) {
                 if (ok) {
 #pragma unroll
@@ -510,23 +731,28 @@ cnx_fwd_kernel(FwdArgs a) {
                         mma16(p1d, w.wp[j], ydf);
                     }
                 }
-                if (ok) {
-                    const int hoff = ((y + 1) * HW + (m + 1)) * CS + 4 * q;
-                    const int64_t off = ((r * s + gy) * (int64_t)s + gx) * 16 + 4 * q;
-                    float res[4], ov[4];
-                    ld4(l.h2s + hoff, res);
+                // residual: h2 of the centre pixel = FiLM(h1); stores are unconditional (vmcnt note)
+                const int hoff = Halo<T>::off(y + 1, m + 1, q);
+                const uint32_t goff = ok ? (uint32_t)((((int64_t)gy * s + gx) * 16 + 4 * q) * sizeof(T)) : BUF_OOB;
+                float n[4], ov[4];
+                ld4(tile + hoff, n);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) ov[i] = p1[i] * w.ls[i] + res[i];
-                    st4((T*)a.o + off, ov);
-                    if constexpr (JVP) {
-                        ld4(l.aux + hoff, res);
+                for (int i = 0; i < 4; ++i) ov[i] = p1[i] * w.ls[i] + (rw.sc1[i] * n[i] + rw.sh[i]);
+                buf_st4(rs_o, goff, ov, (const T*)nullptr);
+                if constexpr (JVP) {
+                    float nd[4], scd4[4], shd4[4];
+                    ld4(tiled + hoff, nd);
+                    ld4(l.fsc + 32 + 4 * q, scd4);
+                    ld4(l.fsc + 48 + 4 * q, shd4);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) ov[i] = p1d[i] * w.ls[i] + res[i];
-                        st4((T*)a.od + off, ov);
-                    }
+                    for (int i = 0; i < 4; ++i) ov[i] = p1d[i] * w.ls[i] + (rw.sc1[i] * nd[i] + scd4[i] * n[i] + shd4[i]);
+                    buf_st4(rs_od, goff, ov, (const T*)nullptr);
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's share of tile t+1 has landed once at most the S_VMEM stores issued after the request are pending
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_VMEM) : "memory");
     }
     if (rcur >= 0) flush_stats(rcur);
 }
@@ -561,25 +787,32 @@ __device__ inline typename Frag<T>::type pix_k_frag(const T* tile, int q, int r)
 }
 
 // MODE 0: dq[r,ch] = sum dy*g1, dbeta += sum dy.
-// MODE 1: dc1 + small-parameter gradients (con_w, con_b, ls, exp_w, exp_b, conv_b).
+// MODE 1: dc1 + small-parameter gradients (con_w, ls, exp_w, exp_b; con_b and conv_b come from cnx_bwd_conv_kernel).
 template <typename T, int MODE>
 __global__ void __launch_bounds__(NT, sizeof(T) == 2 ? 2 : 1)   // bf16: <= 256 registers, two waves per SIMD
 cnx_bwd_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Frag<T>::type frag_t;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, m = lane & 15;
-    Lds<T> l = carve<T>(smem, false, MODE == 1, wave);
+    Lds2<T> l = carve2<T>(smem, false, MODE == 1, wave);
     FwdW<T> w;
     w.load(a.p, q, m);
+    if (wave == 0) stash_conv_w<T>(l.wc0, a.p, q, m, lane);
     // transposed 1x1 weights (A operands of the transposed products)
     const T* pw = (const T*)a.p.con_w;  // [32][16]: dy[e] = sum_c Wp[e][c] dp1[c]
     frag_t wpT[2] = {load_bfrag<T>(pw, 1, 16, 0, 0, q, m), load_bfrag<T>(pw, 1, 16, 0, 16, q, m)};
     const T* ew = (const T*)a.p.exp_w;  // [16][32]: dn1[c] = sum_e We[c][e] de[e]
     frag_t weT[2] = {load_bfrag<T>(ew, 1, 32, 0, 0, q, m), load_bfrag<T>(ew, 1, 32, 16, 0, q, m)};
+    land(wpT[0]); land(wpT[1]); land(weT[0]); land(weT[1]);
     const int s = a.geo.s;
+    const int64_t img = (int64_t)s * s * 16;
     const T* h0 = (const T*)a.h0;
-    const T* dout = (const T*)a.dout;
+    Halo<T> hl;
+    hl.init(s, wave, lane);
+    RowW<T, false> rw;
+    constexpr int S_VMEM = RPW + (MODE == 1 ? RPW : 0);   // dout prefetch loads (+ dc1 stores) after a DMA request
 
     int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
     int64_t t1 = t0 + a.geo.chunk < a.geo.total ? t0 + a.geo.chunk : a.geo.total;
@@ -588,8 +821,9 @@ cnx_bwd_kernel(BwdArgs a) {
     float dqp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dbeta[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     // MODE 1 accumulators
     f32x4 aWp[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, aWe[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-    float dls[4] = {0.f, 0.f, 0.f, 0.f};      // (con_b and conv_b gradients: cnx_bwd_conv_kernel)
+    float dls[4] = {0.f, 0.f, 0.f, 0.f};
     float dbe[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    __amdgpu_buffer_rsrc_t rs_dc = make_rsrc(nullptr, 0);
 
     auto flush_row = [&](int64_t r) {
         if constexpr (MODE == 0) {
@@ -604,36 +838,38 @@ cnx_bwd_kernel(BwdArgs a) {
         }
     };
 
-    // dout of this wave's 4 tile rows, fetched one tile ahead
+    // dout of this wave's 4 tile rows, fetched one tile ahead (unconditional buffer loads: vmcnt note)
     auto load_dout = [&](frag_t d[RPW], const TileCoord& c) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc((const T*)a.dout + c.r * img, (uint32_t)(img * sizeof(T)));
 #pragma unroll
         for (int ri = 0; ri < RPW; ++ri) {
             const int gy = c.y0 + wave * RPW + ri, gxx = c.x0 + m;
-            if (gy < s && gxx < s) d[ri] = *reinterpret_cast<const frag_t*>(dout + ((c.r * s + gy) * (int64_t)s + gxx) * 16 + 4 * q);
-            else frag_raw(d[ri], (T)0, (T)0, (T)0, (T)0);
+            const uint32_t off = (gy < s && gxx < s) ? (uint32_t)((((int64_t)gy * s + gxx) * 16 + 4 * q) * sizeof(T)) : BUF_OOB;
+            d[ri] = buf_ld_frag(rs, off, (const T*)nullptr);
         }
     };
-    HaloRaw<T, false> raw;
     frag_t dnext[RPW];
     TileCoord tnext = tile_coord(a.geo, t0 < t1 ? t0 : 0);
     if (t0 < t1) {
-        halo_load<T, false>(raw, h0, nullptr, nullptr, tnext.r, s, tnext.y0, tnext.x0);
+        hl.request(l.tile0_addr, h0 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
         load_dout(dnext, tnext);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int64_t t = t0; t < t1; ++t) {
         const TileCoord tc = tnext;
         tnext = tile_next(a.geo, tc);
         const int64_t r = tc.r;
         const int y0 = tc.y0, x0 = tc.x0;
         const int gx = x0 + m;
+        const int cur = (int)((t - t0) & 1);
         __syncthreads();
         frag_t dcur[RPW];
 #pragma unroll
-        for (int ri = 0; ri < RPW; ++ri) dcur[ri] = dnext[ri];
+        for (int ri = 0; ri < RPW; ++ri) { dcur[ri] = dnext[ri]; land(dcur[ri]); }
         if (r != rcur) {
             if (rcur >= 0) flush_row(rcur);
             rcur = r;
-            load_film<T, false>(l, a.sc, a.sh, nullptr, nullptr, r);
+            rw.set(l.wc0, w.bc, a.sc, a.sh, nullptr, nullptr, r, q, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -641,14 +877,21 @@ cnx_bwd_kernel(BwdArgs a) {
                     qv[j][i] = a.q[r * 32 + 16 * j + 4 * q + i];
                     if constexpr (MODE == 1) kg[j][i] = a.kG[r * 32 + 16 * j + 4 * q + i];
                 }
-            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { land(qv[j][i]); if constexpr (MODE == 1) land(kg[j][i]); }
+            if constexpr (MODE == 1) rs_dc = make_rsrc((const T*)a.dc1 + r * img, (uint32_t)(img * sizeof(T)));
         }
-        halo_commit<T, false>(l, raw);
-        __syncthreads();
-        if (t + 1 < t1) {
-            halo_load<T, false>(raw, h0, nullptr, nullptr, tnext.r, s, tnext.y0, tnext.x0);
-            load_dout(dnext, tnext);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < t1)
+            hl.request(l.tile0_addr + (cur ^ 1) * (uint32_t)(Halo<T>::ELEMS * sizeof(T)), h0 + tnext.r * img, s, tnext.y0,
+                       tnext.x0, wave);
+        // (past the last tile this re-reads tile t's dout: the instruction count stays fixed)
+        load_dout(dnext, t + 1 < t1 ? tnext : tc);
+        __builtin_amdgcn_sched_barrier(0);
+        const T* tile = l.tile0 + cur * Halo<T>::ELEMS;
+        const bool border = tile_on_border(s, y0, x0);
 #pragma unroll 1
         for (int ri = 0; ri < RPW; ++ri) {
             const int y = wave * RPW + ri;
@@ -659,7 +902,7 @@ cnx_bwd_kernel(BwdArgs a) {
 #pragma unroll
             for (int k = 0; k + 1 < RPW; ++k) dcur[k] = dcur[k + 1];   // rotate: static register indices
             RowFwd<T, false> f;
-            chain_row<T, false, MODE == 1>(l, w, y, q, m, f);
+            chain_row<T, false, MODE == 1>(tile, nullptr, l.wc0, w, rw, border, gy, gx, s, y, q, m, lane, f);
             float dp1[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) dp1[i] = dov[i] * w.ls[i];
@@ -707,7 +950,7 @@ cnx_bwd_kernel(BwdArgs a) {
                 }
                 float dn[4] = {dn1[0], dn1[1], dn1[2], dn1[3]}, dc[4];
                 ln_bwd_a(dn, f.n1, f.rho1, dc);
-                if (ok) st4((T*)a.dc1 + ((r * s + gy) * (int64_t)s + gx) * 16 + 4 * q, dc);
+                buf_st4(rs_dc, ok ? (uint32_t)((((int64_t)gy * s + gx) * 16 + 4 * q) * sizeof(T)) : BUF_OOB, dc, (const T*)nullptr);
                 // weight gradients contract over the 16 pixels of the row: one batched transpose
                 // (pixel-on-lane -> pixel-as-k) of y0, y1, dp1, n1, de0, de1 through the wave scratch
                 *reinterpret_cast<frag_t*>(l.ws + (0 * 16 + m) * CS + 4 * q) = yf[0];
@@ -729,6 +972,8 @@ cnx_bwd_kernel(BwdArgs a) {
                 lds_fence();
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_VMEM) : "memory");   // this wave's share of tile t+1 has landed
     }
     if (rcur >= 0) flush_row(rcur);
     if constexpr (MODE == 0) {
@@ -837,7 +1082,7 @@ cnx_bwd_conv_kernel(BwdArgs a) {
         if (r != rcur) {
             if (rcur >= 0) flush_row(rcur);
             rcur = r;
-            load_film<T, false>(l, a.sc, a.sh, nullptr, nullptr, r);
+            load_film<T, false>(l.fsc, a.sc, a.sh, nullptr, nullptr, r);
 #pragma unroll
             for (int i = 0; i < 4; ++i) sc4[i] = a.sc[r * 16 + 4 * q + i];
             __syncthreads();
@@ -939,6 +1184,29 @@ __global__ void __launch_bounds__(256) ln16_kernel(int64_t npix, const T* x, T* 
     }
 }
 
+// tangent of that LayerNorm for a raw tangent map xd: nd = rho (xd_c - n mean(n xd_c)), xd_c = xd - mean(xd)
+template <typename T>
+__global__ void __launch_bounds__(256) ln16_jvp_kernel(int64_t npix, const T* n, const float* rstd, const T* xd, T* nd) {
+    for (int64_t p = blockIdx.x * 256LL + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+        float v[16], d[16];
+        ld16<T>(n + p * 16, v);
+        ld16<T>(xd + p * 16, d);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sum += d[c];
+        const float md = sum * (1.0f / 16.0f);
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { d[c] -= md; dot += v[c] * d[c]; }
+        dot *= (1.0f / 16.0f);
+        const float rho = rstd[p];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) d[c] = rho * (d[c] - v[c] * dot);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st4(nd + p * 16 + 4 * i, d + 4 * i);
+    }
+}
+
 __global__ void grn_finalize_kernel(int64_t R, const float* S1, const float* S2, float* G, float* qo, float* qd) {
     const int64_t r = blockIdx.x * (int64_t)blockDim.x / 32 + threadIdx.x / 32;
     const int c = threadIdx.x & 31;
@@ -987,6 +1255,7 @@ inline bool params_ok(const mfc_cnx_params* p) {
 }
 
 static const int64_t MAX_BLOCKS = getenv("MFC_CNX_MAX_BLOCKS") ? atoll(getenv("MFC_CNX_MAX_BLOCKS")) : 2048;
+constexpr int MAX_S = 8000;   // one [s, s, 16] fp32 image must stay below the 4 GiB a buffer resource addresses
 
 template <typename K, typename A>
 inline int launch_k(K kern, int64_t grid, size_t lds, hipStream_t st, const A& args) {
@@ -997,7 +1266,7 @@ inline int launch_k(K kern, int64_t grid, size_t lds, hipStream_t st, const A& a
 
 template <typename T>
 int fwd_launch(bool jvp, int mode, const FwdArgs& a, int64_t grid, hipStream_t st) {
-    const size_t lds = lds_bytes<T>(jvp, false);
+    const size_t lds = lds2_bytes<T>(jvp, false);
     if (jvp) {
         if (mode == 0) return launch_k(cnx_fwd_kernel<T, true, 0>, grid, lds, st, a);
         return launch_k(cnx_fwd_kernel<T, true, 1>, grid, lds, st, a);
@@ -1006,21 +1275,22 @@ int fwd_launch(bool jvp, int mode, const FwdArgs& a, int64_t grid, hipStream_t s
     return launch_k(cnx_fwd_kernel<T, false, 1>, grid, lds, st, a);
 }
 
-int fwd_common(int dtype, int mode, int64_t R, int s, const void* h0, const float* rho0, const void* h0dot,
+int fwd_common(int dtype, int mode, int64_t R, int s, const void* h0, const void* h0dot,
                const float* scale, const float* shift, const float* scaledot, const float* shiftdot,
                const mfc_cnx_params* p, float* S1, float* S2, const float* q, const float* qdot,
                void* o, void* odot, void* stream) {
     if (!h0 || !scale || !shift || !params_ok(p)) return MFC_EFAULT;
     if (R <= 0 || s <= 0) return MFC_EINVAL;
+    if (s > MAX_S) return MFC_ENOSYS;
     if (dtype != MFC_F32 && dtype != MFC_BF16) return MFC_EINVAL;
     const bool jvp = h0dot != nullptr;
-    if (jvp && (!scaledot || !shiftdot || !rho0)) return MFC_EFAULT;
+    if (jvp && (!scaledot || !shiftdot)) return MFC_EFAULT;
     if (mode == 0 && (!S1 || (jvp && !S2))) return MFC_EFAULT;
     if (mode == 1 && (!q || !o || (jvp && (!qdot || !odot)))) return MFC_EFAULT;
     FwdArgs a;
     int64_t grid;
     a.geo = make_geo(R, s, MAX_BLOCKS, grid);
-    a.h0 = h0; a.h0d = h0dot; a.rho = rho0; a.sc = scale; a.sh = shift; a.scd = scaledot; a.shd = shiftdot;
+    a.h0 = h0; a.h0d = h0dot; a.sc = scale; a.sh = shift; a.scd = scaledot; a.shd = shiftdot;
     a.p = to_dev(p); a.S1 = S1; a.S2 = S2; a.q = q; a.qd = qdot; a.o = o; a.od = odot;
     static const int dbg = getenv("MFC_CNX_DBG") ? atoi(getenv("MFC_CNX_DBG")) : 0;
     a.dbg = dbg;
@@ -1030,19 +1300,19 @@ int fwd_common(int dtype, int mode, int64_t R, int s, const void* h0, const floa
 
 }  // namespace
 
-extern "C" int mfc_cnx_stats(int dtype, int64_t R, int s, const void* h1, const float* rho0, const void* h0dot,
+extern "C" int mfc_cnx_stats(int dtype, int64_t R, int s, const void* h1, const void* h1dot,
                              const float* scale, const float* shift, const float* scaledot,
                              const float* shiftdot, const mfc_cnx_params* p, float* S1, float* S2,
                              void* stream) {
-    return fwd_common(dtype, 0, R, s, h1, rho0, h0dot, scale, shift, scaledot, shiftdot, p, S1, S2, nullptr, nullptr,
+    return fwd_common(dtype, 0, R, s, h1, h1dot, scale, shift, scaledot, shiftdot, p, S1, S2, nullptr, nullptr,
                       nullptr, nullptr, stream);
 }
 
-extern "C" int mfc_cnx_apply(int dtype, int64_t R, int s, const void* h1, const float* rho0, const void* h0dot,
+extern "C" int mfc_cnx_apply(int dtype, int64_t R, int s, const void* h1, const void* h1dot,
                              const float* scale, const float* shift, const float* scaledot,
                              const float* shiftdot, const mfc_cnx_params* p, const float* q, const float* qdot,
                              void* o, void* odot, void* stream) {
-    return fwd_common(dtype, 1, R, s, h1, rho0, h0dot, scale, shift, scaledot, shiftdot, p, nullptr, nullptr, q, qdot,
+    return fwd_common(dtype, 1, R, s, h1, h1dot, scale, shift, scaledot, shiftdot, p, nullptr, nullptr, q, qdot,
                       o, odot, stream);
 }
 
@@ -1071,14 +1341,15 @@ extern "C" int mfc_cnx_bwd_stats(int dtype, int64_t R, int s, const void* h0, co
                                  float* dq, float* dbeta, void* stream) {
     if (!h0 || !scale || !shift || !params_ok(p) || !q || !dout || !dq || !dbeta) return MFC_EFAULT;
     if (R <= 0 || s <= 0 || (dtype != MFC_F32 && dtype != MFC_BF16)) return MFC_EINVAL;
+    if (s > MAX_S) return MFC_ENOSYS;
     BwdArgs a = {};
     int64_t grid;
     a.geo = make_geo(R, s, MAX_BLOCKS, grid);
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(nullptr);
     a.g.beta = dbeta; a.q = q; a.dout = dout; a.dq = dq;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFC_F32) return launch_k(cnx_bwd_kernel<float, 0>, grid, lds_bytes<float>(false, false), st, a);
-    return launch_k(cnx_bwd_kernel<u16, 0>, grid, lds_bytes<u16>(false, false), st, a);
+    if (dtype == MFC_F32) return launch_k(cnx_bwd_kernel<float, 0>, grid, lds2_bytes<float>(false, false), st, a);
+    return launch_k(cnx_bwd_kernel<u16, 0>, grid, lds2_bytes<u16>(false, false), st, a);
 }
 
 extern "C" int mfc_cnx_bwd_main(int dtype, int64_t R, int s, const void* h0, const float* scale,
@@ -1087,14 +1358,15 @@ extern "C" int mfc_cnx_bwd_main(int dtype, int64_t R, int s, const void* h0, con
     if (!h0 || !scale || !shift || !params_ok(p) || !q || !kG || !dout || !dc1 || !g) return MFC_EFAULT;
     if (!g->con_w || !g->con_b || !g->ls || !g->exp_w || !g->exp_b || !g->conv_b) return MFC_EFAULT;
     if (R <= 0 || s <= 0 || (dtype != MFC_F32 && dtype != MFC_BF16)) return MFC_EINVAL;
+    if (s > MAX_S) return MFC_ENOSYS;
     BwdArgs a = {};
     int64_t grid;
     a.geo = make_geo(R, s, MAX_BLOCKS, grid);
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(g);
     a.q = q; a.kG = kG; a.dout = dout; a.dc1 = dc1;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFC_F32) return launch_k(cnx_bwd_kernel<float, 1>, grid, lds_bytes<float>(false, true), st, a);
-    return launch_k(cnx_bwd_kernel<u16, 1>, grid, lds_bytes<u16>(false, true), st, a);
+    if (dtype == MFC_F32) return launch_k(cnx_bwd_kernel<float, 1>, grid, lds2_bytes<float>(false, true), st, a);
+    return launch_k(cnx_bwd_kernel<u16, 1>, grid, lds2_bytes<u16>(false, true), st, a);
 }
 
 extern "C" int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, const float* rho0,
@@ -1105,6 +1377,7 @@ extern "C" int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, con
         !dshift)
         return MFC_EFAULT;
     if (R <= 0 || s <= 0 || (dtype != MFC_F32 && dtype != MFC_BF16)) return MFC_EINVAL;
+    if (s > MAX_S) return MFC_ENOSYS;
     BwdArgs a = {};
     int64_t grid;
     a.geo = make_geo(R, s, MAX_BLOCKS, grid);
@@ -1127,5 +1400,21 @@ extern "C" int mfc_ln16_fwd(int dtype, int64_t n_pixels, const void* x, void* y,
     else
         hipLaunchKernelGGL(ln16_kernel<u16>, dim3((unsigned)grid), dim3(256), 0, st, n_pixels, (const u16*)x, (u16*)y,
                            rstd);
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_ln16_jvp(int dtype, int64_t n_pixels, const void* n, const float* rstd, const void* xdot,
+                            void* ndot, void* stream) {
+    if (!n || !rstd || !xdot || !ndot) return MFC_EFAULT;
+    if (n_pixels <= 0 || (dtype != MFC_F32 && dtype != MFC_BF16)) return MFC_EINVAL;
+    int64_t grid = ceil_div64(n_pixels, 256);
+    if (grid > 16384) grid = 16384;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_F32)
+        hipLaunchKernelGGL(ln16_jvp_kernel<float>, dim3((unsigned)grid), dim3(256), 0, st, n_pixels, (const float*)n,
+                           rstd, (const float*)xdot, (float*)ndot);
+    else
+        hipLaunchKernelGGL(ln16_jvp_kernel<u16>, dim3((unsigned)grid), dim3(256), 0, st, n_pixels, (const u16*)n, rstd,
+                           (const u16*)xdot, (u16*)ndot);
     return mfc_launch_status();
 }

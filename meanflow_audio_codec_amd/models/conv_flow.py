@@ -197,9 +197,9 @@ class ConditionalConvFlow:
             O = ctx.O[i * R:i * R + Rt] if save else Os
             rho = ctx.rho[i] if save else rhos
             # h0 = g1 W2 + b2 with the block's first LayerNorm fused into the epilogue: the primal rows of H0
-            # hold h1 = LN(h0), rho its per-pixel 1/sigma; tangent rows stay raw (h0dot)
+            # hold h1 = LN(h0), rho its per-pixel 1/sigma; the tangent rows get the tangent of that LayerNorm
             ops.gemm(g1, w[f"{b}/input_proj2/kernel"], bias=w[f"{b}/input_proj2/bias"], bias_rows=R, out=H0,
-                     ln_rstd=rho)
+                     ln_rstd=rho, ln_tangent=True)
             cp = dense(cstack, w[f"{b}/conditioning_layer/kernel"], w[f"{b}/conditioning_layer/bias"], bias_rows=R)
             sc, sh = cp[:R, :16].contiguous(), cp[:R, 16:].contiguous()
             cw = self._cnx_w(w, i)
@@ -207,7 +207,7 @@ class ConditionalConvFlow:
             if n_tan:
                 scd, shd = cp[R:, :16].contiguous(), cp[R:, 16:].contiguous()
                 _, _, G, q = ops.cnx_forward(H0[:n_tan], sc[:n_tan], sh[:n_tan], cw, s, h0dot=H0[R:],
-                                             scaledot=scd, shiftdot=shd, out=O[:n_tan], outdot=O[R:], rho0=rho)
+                                             scaledot=scd, shiftdot=shd, out=O[:n_tan], outdot=O[R:])
                 Gs.append(G); qs.append(q)
             if R > n_tan:
                 _, _, G, q = ops.cnx_forward(H0[n_tan:R], sc[n_tan:], sh[n_tan:], cw, s, out=O[n_tan:R])

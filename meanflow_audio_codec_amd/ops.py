@@ -65,6 +65,17 @@ def _cnx_struct(tensors: dict) -> _lib.CnxParams:
     return s
 
 
+def ln16_jvp(n, rstd, xdot, out=None):
+    """Tangent of the first LayerNorm: ``n``, ``rstd`` from ln16 (or the fused epilogue), ``xdot`` the raw tangent."""
+    assert n.is_contiguous() and xdot.is_contiguous() and xdot.shape == n.shape and xdot.dtype == n.dtype
+    assert rstd.dtype == torch.float32 and rstd.is_contiguous() and rstd.numel() * 16 == n.numel()
+    if out is None:
+        out = torch.empty_like(xdot)
+    _lib.check(_lib.lib().mfc_ln16_jvp(_lib.dtype_code(n.dtype), n.numel() // 16, n.data_ptr(), rstd.data_ptr(),
+                                       xdot.data_ptr(), out.data_ptr(), _lib.stream_ptr()), "mfc_ln16_jvp")
+    return out
+
+
 def cnx_check_weights(w: dict, dtype) -> None:
     shapes = {"conv_w": (3, 3, 16, 16), "conv_b": (16,), "exp_w": (16, 32), "exp_b": (32,),
               "grn_gamma": (32,), "grn_beta": (32,), "con_w": (32, 16), "con_b": (16,), "ls": (16,)}
@@ -95,9 +106,9 @@ def ln16(x, want_rstd=True):
 
 
 def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, shiftdot=None, out=None,
-                outdot=None, rho0=None):
-    """o = ConvNeXtBlock(FiLM(h1)) on [R, s, s, 16] where ``h0`` holds h1 = LN(h0) (see ln16 / the
-    MFC_GEMM_LN16 epilogue), ``rho0`` its per-pixel 1/sigma and ``h0dot`` the RAW tangent of h0;
+                outdot=None):
+    """o = ConvNeXtBlock(FiLM(h1)) on [R, s, s, 16] where ``h0`` holds h1 = LN(h0) and ``h0dot`` the
+    tangent of that LayerNorm (see ln16 / ln16_jvp, or the MFC_GEMM_LN16 / LN16T epilogue);
     returns (o, odot, G, q).  Runs mfc_cnx_stats -> mfc_grn_finalize -> mfc_cnx_apply."""
     _lib.require_cuda(h0)
     R = h0.shape[0]
@@ -109,7 +120,6 @@ def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, sh
     if jvp:
         assert h0dot.is_contiguous() and h0dot.shape == h0.shape and h0dot.dtype == h0.dtype
         _film(scaledot, R), _film(shiftdot, R)
-        assert rho0 is not None and rho0.dtype == torch.float32 and rho0.is_contiguous() and rho0.numel() >= R * s * s
     L = _lib.lib()
     st = _lib.stream_ptr()
     ps = _cnx_struct(w)
@@ -118,14 +128,14 @@ def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, sh
     G = torch.empty((R, 32), dtype=torch.float32, device=dev)
     q = torch.empty_like(G)
     qd = torch.empty_like(G) if jvp else None
-    _lib.check(L.mfc_cnx_stats(dt, R, s, h0.data_ptr(), _lib.ptr(rho0), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
+    _lib.check(L.mfc_cnx_stats(dt, R, s, h0.data_ptr(), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
                                _lib.ptr(scaledot), _lib.ptr(shiftdot), ctypes.byref(ps), S[0].data_ptr(),
                                S[1].data_ptr() if jvp else None, st), "mfc_cnx_stats")
     _lib.check(L.mfc_grn_finalize(R, S[0].data_ptr(), S[1].data_ptr() if jvp else None, G.data_ptr(),
                                   q.data_ptr(), _lib.ptr(qd), st), "mfc_grn_finalize")
     o = out if out is not None else torch.empty_like(h0)
     od = (outdot if outdot is not None else torch.empty_like(h0)) if jvp else None
-    _lib.check(L.mfc_cnx_apply(dt, R, s, h0.data_ptr(), _lib.ptr(rho0), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
+    _lib.check(L.mfc_cnx_apply(dt, R, s, h0.data_ptr(), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
                                _lib.ptr(scaledot), _lib.ptr(shiftdot), ctypes.byref(ps), q.data_ptr(),
                                _lib.ptr(qd), o.data_ptr(), _lib.ptr(od), st), "mfc_cnx_apply")
     return o, od, G, q

@@ -59,8 +59,8 @@ def test_forward_and_jvp(dtype, tol, R, s):
     w = _weights(p, dtype)
     f32 = lambda t: t.float().contiguous().cuda()
     h1, rho = ops.ln16(h0.to(dtype).cuda())          # the first LayerNorm is a separate (GEMM-fused) step
-    o, od, G, q = ops.cnx_forward(h1, f32(sc), f32(sh), w, s, h0dot=h0d.to(dtype).cuda(), scaledot=f32(scd),
-                                  shiftdot=f32(shd), rho0=rho)
+    h1d = ops.ln16_jvp(h1, rho, h0d.to(dtype).cuda())  # ... and so is its tangent
+    o, od, G, q = ops.cnx_forward(h1, f32(sc), f32(sh), w, s, h0dot=h1d, scaledot=f32(scd), shiftdot=f32(shd))
     assert _rel(o, o_ref) < tol, ("primal", _rel(o, o_ref))
     assert _rel(od, od_ref) < tol, ("tangent", _rel(od, od_ref))
     # primal-only entry gives the same primal

@@ -25,7 +25,7 @@ o, _, G, q = ops.cnx_forward(h0, sc, sh, w, s)
 for rep in range(3):
     _lib.enable_timing()
     ops.cnx_forward(h0, sc, sh, w, s)
-    ops.cnx_forward(h0, sc, sh, w, s, h0dot=h0d, scaledot=sc, shiftdot=sh, rho0=rho)
+    ops.cnx_forward(h0, sc, sh, w, s, h0dot=h0d, scaledot=sc, shiftdot=sh)
     ops.cnx_backward(h0, sc, sh, w, s, G, q, dout, grads, rho0=rho)
     torch.cuda.synchronize()
     rec = _lib.disable_timing()
@@ -35,5 +35,5 @@ if True:
         if not name.startswith("mfc_cnx"):
             continue
         ms = a.elapsed_time(b)
-        jvp = nn[2] if name in ("mfc_cnx_stats", "mfc_cnx_apply") else False
+        jvp = nn[1] if name in ("mfc_cnx_stats", "mfc_cnx_apply") else False
         print(f"{name:22s} jvp={int(jvp)} {ms:8.3f} ms  {ms * 1e6 / px:7.2f} ns/pixel")
