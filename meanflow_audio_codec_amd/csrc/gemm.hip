@@ -361,6 +361,7 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     typedef Frag<T>::type frag_t;
     __shared__ __attribute__((aligned(16))) T Bs[NS_K * NS_LDR];
     __shared__ __attribute__((aligned(16))) float slab[4][16 * 68];
+    __shared__ __attribute__((aligned(16))) float bias_s[NS_BN];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, r = lane & 15;
@@ -424,16 +425,10 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     for (; tile < ntiles; tile += gridDim.x) {
         const int64_t col0 = tile * NS_BN + lc;
         const bool colok = col0 < N;
-        float bias16[16];
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_bias, colok ? (uint32_t)((col0 + 4 * k4) * 4) : NS_OOB, 0, 0);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t e = t[k];   // (bit_cast of a vector-element lvalue reads element 0 with this hipcc)
-                bias16[4 * k4 + k] = __builtin_bit_cast(float, e);
-            }
-        }
+        // the tile's 64 bias values: 16 lanes x 16 bytes, parked in LDS after the MFMAs (no registers held across them)
+        const u32x4 bias_v = __builtin_amdgcn_raw_buffer_load_b128(
+            rs_bias, (threadIdx.x < 16 && tile * NS_BN + 4 * threadIdx.x < N) ? (uint32_t)((tile * NS_BN + 4 * threadIdx.x) * 4) : NS_OOB, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // keep it OLDER than the B request below (in-order vmcnt)
         // prefetch (past the end: re-request this tile, never committed -- keeps the instruction unconditional)
         {
             const int64_t nt = tile + gridDim.x < ntiles ? tile + gridDim.x : tile;
@@ -458,12 +453,14 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mma16(acc[i][j], af[i][c], bf[j]);
         }
+        if (threadIdx.x < 16) *reinterpret_cast<u32x4*>(bias_s + 4 * threadIdx.x) = bias_v;
         __syncthreads();   // B tile consumed: the next iteration may overwrite it while slower waves are in the epilogue
 
         // epilogue: 16 rows at a time through the wave's slab, one lane = 16 consecutive columns of a row
-        float npr[16], rho_pr = 0.f;
+        uint32_t npr[8];       // the normalised primal of a (primal, tangent) tile pair, as stored (bf16 pairs)
+        float rho_pr = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) npr[k] = 0.f;
+        for (int k = 0; k < 8; ++k) npr[k] = 0u;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -482,13 +479,14 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
             const int64_t row0 = 16 * (int64_t)(mt[i] < 0 ? 0 : mt[i]);
             const int64_t rows_valid = mt[i] < 0 ? 0 : (g.M - row0 < 16 ? g.M - row0 : 16);
             const int64_t rows_bias = g.bias_rows - row0;      // rows [0, rows_bias) of the tile take the bias
-            if (rows_bias >= 16) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] += bias16[k];
-            } else if (rows_bias > 0) {
+            if (rows_bias > 0) {
                 const bool hb = lr < rows_bias;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] += hb ? bias16[k] : 0.f;
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + lc + 4 * k4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[4 * k4 + k] += hb ? b4[k] : 0.f;
+                }
             }
             if (has_alpha) {
 #pragma unroll
@@ -497,9 +495,15 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
             if (kind[i] == 1) {
                 rho_pr = ln16_lane(v);
 #pragma unroll
-                for (int k = 0; k < 16; ++k) npr[k] = v[k];
+                for (int k = 0; k < 8; ++k) npr[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
             } else if (kind[i] == 2) {
-                ln16_tangent_lane(v, npr, rho_pr);
+                float n[16];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    n[2 * k] = __builtin_bit_cast(float, (uint32_t)(npr[k] << 16));
+                    n[2 * k + 1] = __builtin_bit_cast(float, (uint32_t)(npr[k] & 0xffff0000u));
+                }
+                ln16_tangent_lane(v, n, rho_pr);
             }
             {   // 1/sigma of the LN16 primal rows (empty resource otherwise)
                 const uint32_t bytes = kind[i] == 1 ? (uint32_t)(rows_valid * (N >> 4) * 4) : 0u;
