@@ -4,6 +4,7 @@
 // loss with its gradient seed, column sums for bias gradients, axpby and the
 // fused AdamW update.
 #include "mfc_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -323,6 +324,57 @@ __global__ void adamw_kernel(int64_t n, float* p, u16* pw, const TG* g, float gs
     }
 }
 
+// 4 elements per lane: 16-byte loads/stores of p, m, v, 8/16-byte of the gradient, 8-byte of the bf16 copy.
+// NT: non-temporal (streaming) accesses -- every byte is touched exactly once per step.
+template <typename TG, bool NT>
+__global__ void __launch_bounds__(ET)
+adamw_vec_kernel(int64_t n4, float* p, u16* pw, const TG* g, float gscale, float* m, float* v,
+                 float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    const float ib1 = 1.0f / bc1, ib2 = 1.0f / bc2;
+    for (int64_t o = blockIdx.x * (int64_t)ET + threadIdx.x; o < n4; o += (int64_t)gridDim.x * ET) {
+        f4 gv;
+        if constexpr (sizeof(TG) == 4) {
+            const f4* gp = reinterpret_cast<const f4*>(g) + o;
+            gv = NT ? __builtin_nontemporal_load(gp) : *gp;
+        } else {
+            const u2* gp = reinterpret_cast<const u2*>(g) + o;
+            const u2 t = NT ? __builtin_nontemporal_load(gp) : *gp;
+            gv = f4{__builtin_bit_cast(float, (uint32_t)(t[0] << 16)), __builtin_bit_cast(float, (uint32_t)(t[0] & 0xffff0000u)),
+                    __builtin_bit_cast(float, (uint32_t)(t[1] << 16)), __builtin_bit_cast(float, (uint32_t)(t[1] & 0xffff0000u))};
+        }
+        f4* mp = reinterpret_cast<f4*>(m) + o;
+        f4* vp = reinterpret_cast<f4*>(v) + o;
+        f4* pp = reinterpret_cast<f4*>(p) + o;
+        const f4 m0 = NT ? __builtin_nontemporal_load(mp) : *mp;
+        const f4 v0 = NT ? __builtin_nontemporal_load(vp) : *vp;
+        const f4 p0 = NT ? __builtin_nontemporal_load(pp) : *pp;
+        f4 mm, vv, np;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gv[k] * gscale;
+            mm[k] = b1 * m0[k] + (1.0f - b1) * gk;
+            vv[k] = b2 * v0[k] + (1.0f - b2) * gk * gk;
+            const float upd = (mm[k] / bc1) / (sqrtf(vv[k] / bc2) + eps) + wd * p0[k];
+            np[k] = p0[k] - lr * upd;
+        }
+        (void)ib1; (void)ib2;
+        if (NT) {
+            __builtin_nontemporal_store(mm, mp);
+            __builtin_nontemporal_store(vv, vp);
+            __builtin_nontemporal_store(np, pp);
+        } else {
+            *mp = mm; *vp = vv; *pp = np;
+        }
+        if (pw) {
+            const u2 w = {pack_bf16x2(np[0], np[1]), pack_bf16x2(np[2], np[3])};
+            u2* wp = reinterpret_cast<u2*>(pw) + o;
+            if (NT) __builtin_nontemporal_store(w, wp); else *wp = w;
+        }
+    }
+}
+
 }  // namespace
 
 #define DT_OK(dt) ((dt) == MFC_F32 || (dt) == MFC_BF16)
@@ -490,11 +542,31 @@ extern "C" int mfc_adamw(int grad_dtype, int64_t n, float* p, void* p_bf16, cons
     if (n <= 0 || step < 1 || !DT_OK(grad_dtype)) return MFC_EINVAL;
     const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
     hipStream_t st = (hipStream_t)stream;
+    static const int mode = getenv("MFC_ADAMW_MODE") ? atoi(getenv("MFC_ADAMW_MODE")) : 1;
+    static const int64_t vblocks = getenv("MFC_ADAMW_BLOCKS") ? atoll(getenv("MFC_ADAMW_BLOCKS")) : 65536;
+    const bool aligned = (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g | (uintptr_t)p_bf16) & 15) == 0;
+    int64_t done = 0;
+    if (mode > 0 && aligned && n >= 4) {
+        const int64_t n4 = n / 4;
+        int64_t b = ceil_div64(n4, ET);
+        if (b > vblocks) b = vblocks;
+#define MFC_ADAMW_LAUNCH(TG, NTF)                                                                                  \
+        hipLaunchKernelGGL((adamw_vec_kernel<TG, NTF>), dim3((unsigned)b), dim3(ET), 0, st, n4, p, (u16*)p_bf16,   \
+                           (const TG*)g, grad_scale, m, v, lr, b1, b2, eps, wd, bc1, bc2)
+        if (grad_dtype == MFC_F32) { if (mode == 2) MFC_ADAMW_LAUNCH(float, true); else MFC_ADAMW_LAUNCH(float, false); }
+        else { if (mode == 2) MFC_ADAMW_LAUNCH(u16, true); else MFC_ADAMW_LAUNCH(u16, false); }
+#undef MFC_ADAMW_LAUNCH
+        done = n4 * 4;
+        if (done == n) return mfc_launch_status();
+    }
+    // scalar path: everything when unaligned, else the < 4 element tail
+    const int64_t rem = n - done;
+    u16* pwt = p_bf16 ? (u16*)p_bf16 + done : nullptr;
     if (grad_dtype == MFC_F32)
-        hipLaunchKernelGGL(adamw_kernel<float>, dim3(grid_for(n)), dim3(ET), 0, st, n, p, (u16*)p_bf16,
-                           (const float*)g, grad_scale, m, v, lr, b1, b2, eps, wd, bc1, bc2);
+        hipLaunchKernelGGL(adamw_kernel<float>, dim3(grid_for(rem)), dim3(ET), 0, st, rem, p + done, pwt,
+                           (const float*)g + done, grad_scale, m + done, v + done, lr, b1, b2, eps, wd, bc1, bc2);
     else
-        hipLaunchKernelGGL(adamw_kernel<u16>, dim3(grid_for(n)), dim3(ET), 0, st, n, p, (u16*)p_bf16,
-                           (const u16*)g, grad_scale, m, v, lr, b1, b2, eps, wd, bc1, bc2);
+        hipLaunchKernelGGL(adamw_kernel<u16>, dim3(grid_for(rem)), dim3(ET), 0, st, rem, p + done, pwt,
+                           (const u16*)g + done, grad_scale, m + done, v + done, lr, b1, b2, eps, wd, bc1, bc2);
     return mfc_launch_status();
 }

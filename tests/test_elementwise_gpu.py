@@ -123,20 +123,36 @@ def test_gelu_colsum_axpby_cast():
     assert torch.equal(ops.cast(a.bfloat16(), torch.float32), a.bfloat16().float())
 
 
-def test_adamw_matches_oracle():
+@pytest.mark.parametrize("n", [5000, 5003, 3])
+def test_adamw_matches_oracle(n):
+    """4-wide vector path, its < 4 element scalar tail, and the all-scalar path."""
     from meanflow_audio_codec_amd import ops
     g = torch.Generator().manual_seed(0)
-    p = torch.randn(5000, generator=g)
-    m, v = torch.zeros(5000), torch.zeros(5000)
+    p = torch.randn(n, generator=g)
+    m, v = torch.zeros(n), torch.zeros(n)
     pd, md, vd = p.double(), m.double(), v.double()
     pg, mg, vg = p.cuda(), m.cuda(), v.cuda()
     pw = pg.bfloat16()
     for step in range(1, 5):
-        gr = torch.randn(5000, generator=g)
+        gr = torch.randn(n, generator=g)
         pd, md, vd = fo.adamw_step(pd, gr.double(), md, vd, step, 1e-2, 1e-2)
         ops.adamw(pg, gr.cuda(), mg, vg, lr=1e-2, wd=1e-2, step=step, p_bf16=pw)
     assert (pg.double().cpu() - pd).abs().max() < 1e-5
     assert (mg.double().cpu() - md).abs().max() < 1e-6 and (vg.double().cpu() - vd).abs().max() < 1e-6
     assert torch.equal(pw, pg.bfloat16())
     # bf16 gradient input
-    ops.adamw(pg, torch.randn(5000).cuda().bfloat16(), mg, vg, lr=1e-2, wd=0.0, step=5)
+    ops.adamw(pg, torch.randn(n).cuda().bfloat16(), mg, vg, lr=1e-2, wd=0.0, step=5)
+
+
+def test_adamw_unaligned_views():
+    """Pointers that are not 16-byte aligned take the scalar kernel and give the same update."""
+    from meanflow_audio_codec_amd import ops
+    g = torch.Generator().manual_seed(1)
+    n = 1024
+    p, gr = torch.randn(n + 1, generator=g).cuda(), torch.randn(n + 1, generator=g).cuda()
+    m1, v1, m2, v2 = (torch.zeros(n + 1).cuda() for _ in range(4))
+    pa, pb = p.clone(), p.clone()
+    ops.adamw(pa[1:], gr[1:], m1[1:], v1[1:], lr=1e-2, wd=1e-2, step=1)          # offset by 4 bytes
+    pc, gc, mc, vc = pb[1:].clone(), gr[1:].clone(), m2[1:].clone(), v2[1:].clone()  # aligned copies
+    ops.adamw(pc, gc, mc, vc, lr=1e-2, wd=1e-2, step=1)
+    assert torch.equal(pa[1:], pc) and torch.equal(m1[1:], mc) and torch.equal(v1[1:], vc)
