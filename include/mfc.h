@@ -180,6 +180,10 @@ int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h1, const float* r
                      const float* shift, const mfc_cnx_params* p, const void* dc1, const void* dout,
                      void* dh0, const mfc_cnx_grads* g, float* dscale, float* dshift, void* stream);
 
+/* Tuning / test hook: the persistent ConvNeXt kernels launch at most this many workgroups (default 2048, env
+ * MFC_CNX_MAX_BLOCKS), each walking a contiguous range of tiles.  n > 0 sets it; returns the previous value. */
+int64_t mfc_cnx_max_blocks(int64_t n);
+
 /* First LayerNorm of the block (conv_flow.py:181, nn.LayerNorm over the 16 channels of each pixel):
  * y = LN_16(x) [n_pixels,16] dtype, rstd[n_pixels] fp32 (may be NULL).  The hot path fuses this into the
  * producing product (mfc_gemm flag MFC_GEMM_LN16); this entry point is the standalone form. */

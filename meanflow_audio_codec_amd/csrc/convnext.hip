@@ -1005,33 +1005,66 @@ cnx_bwd_kernel(BwdArgs a) {
     }
 }
 
-// backward pass 3: conv3x3 transpose + conv weight gradient + FiLM/LN0 backward
+// read 16 consecutive halo pixels (row hy, columns hx0..hx0+15) of a DMA tile as an operand that has the PIXEL as k:
+// lane (q, r): elements (pixel hx0+4q+i, channel r)
+template <typename T>
+__device__ inline typename Frag<T>::type pix_k_tile(const T* tile, int hy, int hx0, int q, int r) {
+    if constexpr (sizeof(T) == 2) {
+        // LDS transpose read: lane 4q'+p of group q supplies the address of pixel 4q+q', channels 4p..4p+3
+        const T* p = tile + Halo<T>::off(hy, hx0 + 4 * q + (r >> 2), r & 3);
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+    } else {
+        typename Frag<T>::type f;
+        const int c = r >> 2, w = r & 3;
+        frag_raw(f, tile[Halo<T>::off(hy, hx0 + 4 * q, c) + w], tile[Halo<T>::off(hy, hx0 + 4 * q + 1, c) + w],
+                 tile[Halo<T>::off(hy, hx0 + 4 * q + 2, c) + w], tile[Halo<T>::off(hy, hx0 + 4 * q + 3, c) + w]);
+        return f;
+    }
+}
+
+// backward pass 3: conv3x3 transpose + conv weight gradient + FiLM/LN0 backward.
+// Both halo tiles (h1 and dc1) are verbatim copies and arrive by LDS-DMA (see Halo).  With h2 = (1+scale) h1 +
+// shift the conv weight gradient of one row r splits into
+//     dWc[tap][ic][oc] = (1+scale[ic]) * A[tap][ic][oc] + shift[ic] * B[tap][oc],
+//     A = sum_p h1[p+tap][ic] dc1[p][oc],   B = sum_{p: p+tap inside the image} dc1[p][oc]
+// A is the 9 pixel-contracting MFMAs on the raw tile; B is ONE more MFMA whose A operand is the 0/1 tap-validity
+// mask (row = tap, k = pixel; all ones on interior tiles).  Both are flushed when the workgroup's row r changes.
 template <typename T>
 __global__ void __launch_bounds__(NT)
 cnx_bwd_conv_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Frag<T>::type frag_t;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, m = lane & 15;
-    Lds<T> l = carve<T>(smem, true, false, wave);
+    Lds2<T> l = carve2<T>(smem, true, false, wave);   // tile0: h1 halo, tiled0: dc1 halo
     const T* cw = (const T*)a.p.conv_w;  // [tap][ic][oc]
     frag_t wcT[9];  // A[row=ic][k=oc] of the transposed product dh2^T = Wc dc1^T
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wcT[t] = load_bfrag<T>(cw + t * 256, 1, 16, 0, 0, q, m);
+    for (int t = 0; t < 9; ++t) { wcT[t] = load_bfrag<T>(cw + t * 256, 1, 16, 0, 0, q, m); land(wcT[t]); }
     const int s = a.geo.s;
+    const int64_t img = (int64_t)s * s * 16;
     const T* h0 = (const T*)a.h0;
-    const T* dout = (const T*)a.dout;
     const T* dc1 = (const T*)a.dc1_in;
+    Halo<T> hl;
+    hl.init(s, wave, lane);
+    constexpr int S_VMEM = 3 * RPW;   // dout + rho prefetch loads and dh0 stores issued after a DMA request
+    constexpr uint32_t TB = Halo<T>::ELEMS * sizeof(T);
 
     int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
     int64_t t1 = t0 + a.geo.chunk < a.geo.total ? t0 + a.geo.chunk : a.geo.total;
     int64_t rcur = -1;
-    f32x4 aWc[9];
+    f32x4 aWc[9], aB = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 9; ++t) aWc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dscp[4] = {0.f, 0.f, 0.f, 0.f}, dshp[4] = {0.f, 0.f, 0.f, 0.f};
-    float sc4[4] = {0.f, 0.f, 0.f, 0.f};
+    float sc1[4] = {1.f, 1.f, 1.f, 1.f}, shr[4] = {0.f, 0.f, 0.f, 0.f};         // 1 + scale, shift of channels 4q..4q+3, row rcur
     float dsum[4] = {0.f, 0.f, 0.f, 0.f}, dcsum[4] = {0.f, 0.f, 0.f, 0.f};   // -> d con_b (x ls), d conv_b
+    // tap-validity mask rows: lane row m = tap m (dy = m / 3, dx = m % 3), rows 9..15 are zero
+    const int tdy = m / 3, tdx = m - 3 * tdy;
+    frag_t mk_int;
+    { const float one = m < 9 ? 1.0f : 0.0f; make_frag(mk_int, one, one, one, one); }
+    __amdgpu_buffer_rsrc_t rs_dh = make_rsrc(nullptr, 0);
 
     auto flush_row = [&](int64_t r) {
 #pragma unroll
@@ -1040,79 +1073,90 @@ cnx_bwd_conv_kernel(BwdArgs a) {
             if (m == 0) { atomicAdd(a.dsc + r * 16 + 4 * q + i, v1); atomicAdd(a.dsh + r * 16 + 4 * q + i, v2); }
             dscp[i] = 0.f; dshp[i] = 0.f;
         }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float bt = __shfl(aB[t & 3], (t >> 2) * 16 + m);   // B[tap t][oc = m]
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                atomicAdd(a.g.conv_w + (t * 16 + 4 * q + e) * 16 + m, sc1[e] * aWc[t][e] + shr[e] * bt);
+            aWc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        aB = f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
-    // centre-pixel dout / h0 of this wave's rows, fetched one tile ahead
-    auto load_centre = [&](frag_t d[RPW], frag_t hh[RPW], float rr[RPW], const TileCoord& c) {
+    // centre-pixel dout and 1/sigma of this wave's rows, fetched one tile ahead (unconditional buffer loads)
+    auto load_centre = [&](frag_t d[RPW], float rr[RPW], const TileCoord& c) {
+        const __amdgpu_buffer_rsrc_t rs_d = make_rsrc((const T*)a.dout + c.r * img, (uint32_t)(img * sizeof(T)));
+        const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(a.rho + c.r * (int64_t)s * s, (uint32_t)((int64_t)s * s * 4));
 #pragma unroll
         for (int ri = 0; ri < RPW; ++ri) {
             const int gy = c.y0 + wave * RPW + ri, gxx = c.x0 + m;
-            if (gy < s && gxx < s) {
-                const int64_t pix = (c.r * s + gy) * (int64_t)s + gxx;
-                d[ri] = *reinterpret_cast<const frag_t*>(dout + pix * 16 + 4 * q);
-                hh[ri] = *reinterpret_cast<const frag_t*>(h0 + pix * 16 + 4 * q);
-                rr[ri] = a.rho[pix];
-            } else {
-                frag_raw(d[ri], (T)0, (T)0, (T)0, (T)0);
-                frag_raw(hh[ri], (T)0, (T)0, (T)0, (T)0);
-                rr[ri] = 0.f;
-            }
+            const bool in = gy < s && gxx < s;
+            const int64_t pix = (int64_t)gy * s + gxx;
+            d[ri] = buf_ld_frag(rs_d, in ? (uint32_t)((pix * 16 + 4 * q) * sizeof(T)) : BUF_OOB, (const T*)nullptr);
+            rr[ri] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, in ? (uint32_t)(pix * 4) : BUF_OOB, 0, 0));
         }
     };
-    HaloRaw<T, false> raw, rawd;
-    frag_t dnext[RPW], hnext[RPW];
+    frag_t dnext[RPW];
     float rnext[RPW];
     TileCoord tnext = tile_coord(a.geo, t0 < t1 ? t0 : 0);
     if (t0 < t1) {
-        halo_load<T, false>(raw, h0, nullptr, nullptr, tnext.r, s, tnext.y0, tnext.x0);
-        halo_load<T, false>(rawd, dc1, nullptr, nullptr, tnext.r, s, tnext.y0, tnext.x0);
-        load_centre(dnext, hnext, rnext, tnext);
+        hl.request(l.tile0_addr, h0 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
+        hl.request(l.tiled0_addr, dc1 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
+        load_centre(dnext, rnext, tnext);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int64_t t = t0; t < t1; ++t) {
         const TileCoord tc = tnext;
         tnext = tile_next(a.geo, tc);
         const int64_t r = tc.r;
         const int y0 = tc.y0, x0 = tc.x0;
         const int gx = x0 + m;
+        const int cur = (int)((t - t0) & 1);
         __syncthreads();
-        frag_t dcur[RPW], hcur[RPW];
+        frag_t dcur[RPW];
         float rcur4[RPW];
 #pragma unroll
-        for (int ri = 0; ri < RPW; ++ri) { dcur[ri] = dnext[ri]; hcur[ri] = hnext[ri]; rcur4[ri] = rnext[ri]; }
+        for (int ri = 0; ri < RPW; ++ri) { dcur[ri] = dnext[ri]; rcur4[ri] = rnext[ri]; land(dcur[ri]); land(rcur4[ri]); }
         if (r != rcur) {
             if (rcur >= 0) flush_row(rcur);
             rcur = r;
-            load_film<T, false>(l.fsc, a.sc, a.sh, nullptr, nullptr, r);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sc4[i] = a.sc[r * 16 + 4 * q + i];
-            __syncthreads();
+            for (int i = 0; i < 4; ++i) {
+                sc1[i] = 1.0f + a.sc[r * 16 + 4 * q + i];
+                shr[i] = a.sh[r * 16 + 4 * q + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { land(sc1[i]); land(shr[i]); }
+            rs_dh = make_rsrc((const T*)a.dh0 + r * img, (uint32_t)(img * sizeof(T)));
         }
-        halo_commit<T, false>(l, raw);
-        halo_commit_raw<T>(l.aux, rawd);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < t1) {
-            halo_load<T, false>(raw, h0, nullptr, nullptr, tnext.r, s, tnext.y0, tnext.x0);
-            halo_load<T, false>(rawd, dc1, nullptr, nullptr, tnext.r, s, tnext.y0, tnext.x0);
-            load_centre(dnext, hnext, rnext, tnext);
+            hl.request(l.tile0_addr + (cur ^ 1) * TB, h0 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
+            hl.request(l.tiled0_addr + (cur ^ 1) * TB, dc1 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
         }
+        load_centre(dnext, rnext, t + 1 < t1 ? tnext : tc);
+        __builtin_amdgcn_sched_barrier(0);
+        const T* tile = l.tile0 + cur * Halo<T>::ELEMS;
+        const T* dtile = l.tiled0 + cur * Halo<T>::ELEMS;
+        const bool border = tile_on_border(s, y0, x0);
 #pragma unroll 1
         for (int ri = 0; ri < RPW; ++ri) {
             const int y = wave * RPW + ri;
             const int gy = y0 + y;
-            float dov[4], h1[4];
+            const bool ok = gy < s && gx < s;
+            float dov[4];
             unfrag(dcur[0], dov);
-            unfrag(hcur[0], h1);
             const float rho = rcur4[0];
 #pragma unroll
-            for (int k = 0; k + 1 < RPW; ++k) { dcur[k] = dcur[k + 1]; hcur[k] = hcur[k + 1]; rcur4[k] = rcur4[k + 1]; }
+            for (int k = 0; k + 1 < RPW; ++k) { dcur[k] = dcur[k + 1]; rcur4[k] = rcur4[k + 1]; }
             // dh2 = conv^T(dc1): h2[p] feeds c1[p - (i-1, j-1)] through K[i][j]
             f32x4 dh = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const frag_t ad = *reinterpret_cast<const frag_t*>(
-                        l.aux + ((y + 2 - i) * HW + (m + 2 - j)) * CS + 4 * q);
+                    const frag_t ad = *reinterpret_cast<const frag_t*>(dtile + Halo<T>::off(y + 2 - i, m + 2 - j, q));
                     mma16(dh, wcT[i * 3 + j], ad);
                     if (i == 1 && j == 1) {   // centre tap: this lane's own dc1 (zero outside the image)
                         float dcv[4];
@@ -1123,32 +1167,40 @@ cnx_bwd_conv_kernel(BwdArgs a) {
                 }
 #pragma unroll
             for (int k = 0; k < 4; ++k) dsum[k] += dov[k];
-            // dWc[tap][ic][oc] += sum_pixels h2[p + tap][ic] dc1[p][oc]
+            // A[tap][ic][oc] += sum_pixels h1[p + tap][ic] dc1[p][oc];  B[tap][oc] += sum_{valid} dc1[p][oc]
             {
-                const frag_t bd = pix_k_frag<T>(l.aux + ((y + 1) * HW + 1) * CS, q, m);
+                const frag_t bd = pix_k_tile<T>(dtile, y + 1, 1, q, m);
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const frag_t ah = pix_k_frag<T>(l.h2s + ((y + i) * HW + j) * CS, q, m);
-                        mma16(aWc[i * 3 + j], ah, bd);
-                    }
+                    for (int j = 0; j < 3; ++j) mma16(aWc[i * 3 + j], pix_k_tile<T>(tile, y + i, j, q, m), bd);
+                frag_t mk = mk_int;
+                if (border) {
+                    const bool rowin = (unsigned)(gy + tdy - 1) < (unsigned)s && m < 9;
+                    float mv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mv[i] = (rowin && (unsigned)(x0 + 4 * q + i + tdx - 1) < (unsigned)s) ? 1.0f : 0.0f;
+                    make_frag(mk, mv[0], mv[1], mv[2], mv[3]);
+                }
+                mma16(aB, mk, bd);
             }
-            if (gy < s && gx < s) {
-                const int64_t goff = ((r * s + gy) * (int64_t)s + gx) * 16 + 4 * q;
-                float d2[4], dh1[4], dx[4];
+            {
+                float h1[4], d2[4], dh1[4], dx[4];
+                ld4(tile + Halo<T>::off(y + 1, m + 1, q), h1);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) d2[i] = dh[i] + dov[i];  // residual branch o = ... + h2
+                if (ok) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    dscp[i] += d2[i] * h1[i];
-                    dshp[i] += d2[i];
-                    dh1[i] = d2[i] * (1.0f + sc4[i]);
+                    for (int i = 0; i < 4; ++i) { dscp[i] += d2[i] * h1[i]; dshp[i] += d2[i]; }
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dh1[i] = d2[i] * sc1[i];
                 ln_bwd_a(dh1, h1, rho, dx);
-                st4((T*)a.dh0 + goff, dx);
+                buf_st4(rs_dh, ok ? (uint32_t)((((int64_t)gy * s + gx) * 16 + 4 * q) * sizeof(T)) : BUF_OOB, dx, (const T*)nullptr);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_VMEM) : "memory");   // this wave's share of tile t+1 has landed
     }
     if (rcur >= 0) flush_row(rcur);
 #pragma unroll
@@ -1159,10 +1211,6 @@ cnx_bwd_conv_kernel(BwdArgs a) {
             atomicAdd(a.g.conv_b + 4 * q + i, v2);
         }
     }
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(a.g.conv_w + (t * 16 + 4 * q + e) * 16 + m, aWc[t][e]);
 }
 
 // standalone first LayerNorm (what mfc_gemm's MFC_GEMM_LN16 epilogue fuses): y = LN_16(x), rstd per pixel
@@ -1254,7 +1302,7 @@ inline bool params_ok(const mfc_cnx_params* p) {
            p->con_b && p->ls;
 }
 
-static const int64_t MAX_BLOCKS = getenv("MFC_CNX_MAX_BLOCKS") ? atoll(getenv("MFC_CNX_MAX_BLOCKS")) : 2048;
+static int64_t MAX_BLOCKS = getenv("MFC_CNX_MAX_BLOCKS") ? atoll(getenv("MFC_CNX_MAX_BLOCKS")) : 2048;
 constexpr int MAX_S = 8000;   // one [s, s, 16] fp32 image must stay below the 4 GiB a buffer resource addresses
 
 template <typename K, typename A>
@@ -1384,8 +1432,8 @@ extern "C" int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, con
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(g);
     a.rho = rho0; a.dc1_in = dc1; a.dout = dout; a.dh0 = dh0; a.dsc = dscale; a.dsh = dshift;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFC_F32) return launch_k(cnx_bwd_conv_kernel<float>, grid, lds_bytes<float>(true, false), st, a);
-    return launch_k(cnx_bwd_conv_kernel<u16>, grid, lds_bytes<u16>(true, false), st, a);
+    if (dtype == MFC_F32) return launch_k(cnx_bwd_conv_kernel<float>, grid, lds2_bytes<float>(true, false), st, a);
+    return launch_k(cnx_bwd_conv_kernel<u16>, grid, lds2_bytes<u16>(true, false), st, a);
 }
 
 extern "C" int mfc_ln16_fwd(int dtype, int64_t n_pixels, const void* x, void* y, float* rstd, void* stream) {
@@ -1417,4 +1465,10 @@ extern "C" int mfc_ln16_jvp(int dtype, int64_t n_pixels, const void* n, const fl
         hipLaunchKernelGGL(ln16_jvp_kernel<u16>, dim3((unsigned)grid), dim3(256), 0, st, n_pixels, (const u16*)n, rstd,
                            (const u16*)xdot, (u16*)ndot);
     return mfc_launch_status();
+}
+
+extern "C" int64_t mfc_cnx_max_blocks(int64_t n) {
+    const int64_t old = MAX_BLOCKS;
+    if (n > 0) MAX_BLOCKS = n;
+    return old;
 }
