@@ -160,22 +160,22 @@ int mfc_cnx_apply(int dtype, int64_t R, int s, const void* h1, const void* h1dot
                   const mfc_cnx_params* p, const float* q, const float* qdot,
                   void* o, void* odot, void* stream);
 
-/* backward pass 1: dq[r,ch] += sum_hw dy*g1, dbeta[ch] += sum dy   (dq zeroed by caller) */
+/* backward pass 1: dq[r,ch] += sum_hw dy*g1   (dq zeroed by caller) */
 int mfc_cnx_bwd_stats(int dtype, int64_t R, int s, const void* h0, const float* scale, const float* shift,
                       const mfc_cnx_params* p, const float* q, const void* dout,
-                      float* dq, float* dbeta, void* stream);
+                      float* dq, void* stream);
 
 /* kG[r,ch] = (dL/dG)/G from dq (zero where G == 0); dgamma[ch] += sum_r dq */
 int mfc_grn_bwd_finalize(int64_t R, const float* G, const float* dq, float* kG, float* dgamma, void* stream);
 
 /* backward pass 2: dc1 [R,s,s,16] dtype (gradient at the 3x3 conv output) and the
- * small-parameter gradients except conv_w/grn_gamma/grn_beta. */
+ * gradients of exp_w, exp_b, con_w and ls. */
 int mfc_cnx_bwd_main(int dtype, int64_t R, int s, const void* h0, const float* scale, const float* shift,
                      const mfc_cnx_params* p, const float* q, const float* kG, const void* dout,
                      void* dc1, const mfc_cnx_grads* g, void* stream);
 
-/* backward pass 3: dh0 = LN/FiLM-backward(conv3x3^T(dc1) + dout); conv_w
- * gradient; dscale/dshift [R,16] fp32 (+=, zeroed by caller). */
+/* backward pass 3: dh0 = LN/FiLM-backward(conv3x3^T(dc1) + dout); gradients of conv_w, conv_b, con_b and
+ * grn_beta (the last two are linear in sum_hw dout); dscale/dshift [R,16] fp32 (+=, zeroed by caller). */
 int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h1, const float* rho0, const float* scale,
                      const float* shift, const mfc_cnx_params* p, const void* dc1, const void* dout,
                      void* dh0, const mfc_cnx_grads* g, float* dscale, float* dshift, void* stream);

@@ -13,7 +13,9 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 import torch  # noqa: F401  (loads the ROCm runtime libmfc.so links against)
 
 _HERE = pathlib.Path(__file__).resolve().parent
-LIB_PATH = _HERE / "csrc" / "libmfc.so"
+import os  # noqa: E402
+# MFC_LIB: an alternative build of the same C ABI (A/B timing of two kernel versions in one GPU session)
+LIB_PATH = pathlib.Path(os.environ["MFC_LIB"]) if os.environ.get("MFC_LIB") else _HERE / "csrc" / "libmfc.so"
 HEADER = _HERE.parent / "include" / "mfc.h"
 
 MFC_F32, MFC_BF16 = 0, 1
@@ -47,7 +49,7 @@ SIGNATURES = {
     "mfc_cnx_stats": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_grn_finalize": (c_int, [c_int64, _P, _P, _P, _P, _P, _P]),
     "mfc_cnx_apply": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "mfc_cnx_bwd_stats": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_cnx_bwd_stats": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_grn_bwd_finalize": (c_int, [c_int64, _P, _P, _P, _P, _P]),
     "mfc_cnx_bwd_main": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_cnx_bwd_conv": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

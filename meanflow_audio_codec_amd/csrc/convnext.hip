@@ -49,7 +49,9 @@ struct DevG {
     float* con_w; float* con_b; float* ls;
 };
 
-__device__ inline void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// LDS accesses of one wave execute in order, so a wave reading back its own scratch needs no s_waitcnt between
+// the writes and the reads -- only the compiler must not reorder them
+__device__ inline void lds_fence() { asm volatile("" ::: "memory"); }
 // make a just-loaded value land HERE: left pending, the compiler's wait for it would sit at its first use in
 // the tile loop's common path and (vmcnt being one in-order counter) drain the halo DMA on every tile
 __device__ inline void land(const float& v) { asm volatile("" ::"v"(v)); }
@@ -393,34 +395,37 @@ template <typename T> struct Halo {
 // being branched around, and __builtin_amdgcn_sched_barrier pins them on their side of the request.
 
 template <typename T> struct Lds2 {
-    T* tile0;      // double-buffered halo of h1: buffer b at tile0 + b * Halo<T>::ELEMS
-    T* tiled0;     // ... of its tangent (forward JVP)
-    uint32_t tile0_addr, tiled0_addr;   // their LDS byte addresses (M0 of the DMA)
-    T* wc0;        // [9][64 lanes][4]: the unscaled conv weights as A-operand fragments
-    T* ws;         // per wave [6][16][CS] weight-gradient transpose scratch (backward main)
-    float* fsc;    // [4][16] scale, shift, scaledot, shiftdot of the current row r
+    T* tile0;             // NTILE double-buffered halo tiles: tile k, buffer b at tile0 + (2k + b) * Halo<T>::ELEMS
+    uint32_t tile0_addr;  // LDS byte address of tile0 (M0 of the DMA)
+    T* wc0;               // [9][64 lanes][4]: the unscaled conv weights as A-operand fragments
+    T* ws;                // per wave [6][16][CS] weight-gradient transpose scratch (backward main)
+    float* fsc;           // [4][16] scale, shift, scaledot, shiftdot of the current row r
+    float* rho;           // [2][TH*TW] per-pixel 1/sigma of the tile (backward conv)
+    uint32_t rho_addr;
+    __device__ inline const T* tile(int k, int b) const { return tile0 + (2 * k + b) * Halo<T>::ELEMS; }
+    __device__ inline uint32_t tile_addr(int k, int b) const { return tile0_addr + (2 * k + b) * (uint32_t)(Halo<T>::ELEMS * sizeof(T)); }
 };
 template <typename T>
-__host__ __device__ inline size_t lds2_bytes(bool jvp, bool ws) {
-    size_t b = (size_t)Halo<T>::ELEMS * sizeof(T) * 2 * (jvp ? 2 : 1) + (size_t)9 * 64 * 4 * sizeof(T);
+__host__ __device__ inline size_t lds2_bytes(int ntile, bool ws) {
+    size_t b = (size_t)Halo<T>::ELEMS * sizeof(T) * 2 * ntile + (size_t)9 * 64 * 4 * sizeof(T);
     if (ws) b += (size_t)NWAVES * WS_TILES * 16 * CS * sizeof(T);
     b = (b + 15) & ~(size_t)15;
-    return b + 64 * sizeof(float);
+    return b + 64 * sizeof(float) + 2 * TH * TW * sizeof(float);
 }
 template <typename T>
-__device__ inline Lds2<T> carve2(unsigned char* base, bool jvp, bool ws, int wave) {
+__device__ inline Lds2<T> carve2(unsigned char* base, int ntile, bool ws, int wave) {
     Lds2<T> l;
     T* p = (T*)base;
     const uint32_t base_addr = (uint32_t)(uintptr_t)(lvoid_t*)base;
-    l.tile0 = p; l.tile0_addr = base_addr; p += 2 * Halo<T>::ELEMS;
-    l.tiled0 = p; l.tiled0_addr = base_addr + 2 * Halo<T>::ELEMS * (uint32_t)sizeof(T);
-    if (jvp) p += 2 * Halo<T>::ELEMS;
+    l.tile0 = p; l.tile0_addr = base_addr; p += 2 * ntile * Halo<T>::ELEMS;
     l.wc0 = p; p += 9 * 64 * 4;
     l.ws = p + (size_t)wave * WS_TILES * 16 * CS;
-    size_t b = (size_t)Halo<T>::ELEMS * sizeof(T) * 2 * (jvp ? 2 : 1) + (size_t)9 * 64 * 4 * sizeof(T);
+    size_t b = (size_t)Halo<T>::ELEMS * sizeof(T) * 2 * ntile + (size_t)9 * 64 * 4 * sizeof(T);
     if (ws) b += (size_t)NWAVES * WS_TILES * 16 * CS * sizeof(T);
     b = (b + 15) & ~(size_t)15;
     l.fsc = (float*)(base + b);
+    l.rho = l.fsc + 64;
+    l.rho_addr = base_addr + (uint32_t)b + 64 * (uint32_t)sizeof(float);
     return l;
 }
 
@@ -610,7 +615,7 @@ cnx_fwd_kernel(FwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, m = lane & 15;
-    Lds2<T> l = carve2<T>(smem, JVP, false, wave);
+    Lds2<T> l = carve2<T>(smem, JVP ? 2 : 1, false, wave);   // tile 0: h1, tile 1: its tangent
     FwdW<T> w;
     w.load(a.p, q, m);
     if (wave == 0) stash_conv_w<T>(l.wc0, a.p, q, m, lane);
@@ -649,8 +654,8 @@ cnx_fwd_kernel(FwdArgs a) {
 
     TileCoord tnext = tile_coord(a.geo, t0 < t1 ? t0 : 0);
     if (t0 < t1) {
-        hl.request(l.tile0_addr, h0 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
-        if constexpr (JVP) hl.request(l.tiled0_addr, h0d + tnext.r * img, s, tnext.y0, tnext.x0, wave);
+        hl.request(l.tile_addr(0, 0), h0 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
+        if constexpr (JVP) hl.request(l.tile_addr(1, 0), h0d + tnext.r * img, s, tnext.y0, tnext.x0, wave);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int64_t t = t0; t < t1; ++t) {
@@ -686,13 +691,12 @@ cnx_fwd_kernel(FwdArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < t1 && !(a.dbg & 2)) {
-            constexpr uint32_t TB = Halo<T>::ELEMS * sizeof(T);
-            hl.request(l.tile0_addr + (cur ^ 1) * TB, h0 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
-            if constexpr (JVP) hl.request(l.tiled0_addr + (cur ^ 1) * TB, h0d + tnext.r * img, s, tnext.y0, tnext.x0, wave);
+            hl.request(l.tile_addr(0, cur ^ 1), h0 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
+            if constexpr (JVP) hl.request(l.tile_addr(1, cur ^ 1), h0d + tnext.r * img, s, tnext.y0, tnext.x0, wave);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const T* tile = l.tile0 + cur * Halo<T>::ELEMS;
-        const T* tiled = l.tiled0 + cur * Halo<T>::ELEMS;
+        const T* tile = l.tile(0, cur);
+        const T* tiled = l.tile(JVP ? 1 : 0, cur);
         const bool border = tile_on_border(s, y0, x0);
         const int gx = x0 + m;
 #pragma unroll 1
@@ -767,6 +771,7 @@ struct BwdArgs {
     const float* q; const float* kG;
     const void* dout; const void* dc1_in;
     float* dq; void* dc1; void* dh0; float* dsc; float* dsh;
+    int dbg;
 };
 
 // read a [16 pixel][CS] scratch tile as an operand that has the PIXEL as k:
@@ -789,14 +794,14 @@ __device__ inline typename Frag<T>::type pix_k_frag(const T* tile, int q, int r)
 // MODE 0: dq[r,ch] = sum dy*g1, dbeta += sum dy.
 // MODE 1: dc1 + small-parameter gradients (con_w, ls, exp_w, exp_b; con_b and conv_b come from cnx_bwd_conv_kernel).
 template <typename T, int MODE>
-__global__ void __launch_bounds__(NT, sizeof(T) == 2 ? 2 : 1)   // bf16: <= 256 registers, two waves per SIMD
+__global__ void __launch_bounds__(NT, sizeof(T) == 2 ? (MODE == 0 ? 4 : 2) : 1)   // bf16: <= 128 / 256 registers (4 / 2 waves per SIMD)
 cnx_bwd_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Frag<T>::type frag_t;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, m = lane & 15;
-    Lds2<T> l = carve2<T>(smem, false, MODE == 1, wave);
+    Lds2<T> l = carve2<T>(smem, MODE == 1 ? 2 : 1, MODE == 1, wave);   // tile 0: h1; MODE 1: tile 1 = dout
     FwdW<T> w;
     w.load(a.p, q, m);
     if (wave == 0) stash_conv_w<T>(l.wc0, a.p, q, m, lane);
@@ -812,13 +817,17 @@ cnx_bwd_kernel(BwdArgs a) {
     Halo<T> hl;
     hl.init(s, wave, lane);
     RowW<T, false> rw;
-    constexpr int S_VMEM = RPW + (MODE == 1 ? RPW : 0);   // dout prefetch loads (+ dc1 stores) after a DMA request
+    // VMEM instructions between a DMA request and its wait.  MODE 0 prefetches dout through registers (RPW buffer
+    // loads; it has no stores, so the compiler's own wait for them drains nothing, and a second DMA tile would cost
+    // a workgroup per CU in LDS).  MODE 1 takes dout as a second DMA tile: with a register prefetch the compiler
+    // would wait for most of the RPW dc1 stores at the top of every tile.
+    constexpr int S_VMEM = RPW;
 
     int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
     int64_t t1 = t0 + a.geo.chunk < a.geo.total ? t0 + a.geo.chunk : a.geo.total;
     int64_t rcur = -1;
     float qv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, kg[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    float dqp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dbeta[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float dqp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // (d grn_beta = Wp (ls * sum dout): cnx_bwd_conv_kernel)
     // MODE 1 accumulators
     f32x4 aWp[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, aWe[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
     float dls[4] = {0.f, 0.f, 0.f, 0.f};
@@ -838,9 +847,10 @@ cnx_bwd_kernel(BwdArgs a) {
         }
     };
 
-    // dout of this wave's 4 tile rows, fetched one tile ahead (unconditional buffer loads: vmcnt note)
+    const T* doutp = (const T*)a.dout;
+    // MODE 0: dout of this wave's 4 tile rows, fetched one tile ahead (unconditional buffer loads: vmcnt note)
     auto load_dout = [&](frag_t d[RPW], const TileCoord& c) {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc((const T*)a.dout + c.r * img, (uint32_t)(img * sizeof(T)));
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(doutp + c.r * img, (uint32_t)(img * sizeof(T)));
 #pragma unroll
         for (int ri = 0; ri < RPW; ++ri) {
             const int gy = c.y0 + wave * RPW + ri, gxx = c.x0 + m;
@@ -851,8 +861,9 @@ cnx_bwd_kernel(BwdArgs a) {
     frag_t dnext[RPW];
     TileCoord tnext = tile_coord(a.geo, t0 < t1 ? t0 : 0);
     if (t0 < t1) {
-        hl.request(l.tile0_addr, h0 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
-        load_dout(dnext, tnext);
+        hl.request(l.tile_addr(0, 0), h0 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
+        if constexpr (MODE == 1) hl.request(l.tile_addr(1, 0), doutp + tnext.r * img, s, tnext.y0, tnext.x0, wave);
+        else load_dout(dnext, tnext);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int64_t t = t0; t < t1; ++t) {
@@ -864,8 +875,10 @@ cnx_bwd_kernel(BwdArgs a) {
         const int cur = (int)((t - t0) & 1);
         __syncthreads();
         frag_t dcur[RPW];
+        if constexpr (MODE == 0) {
 #pragma unroll
-        for (int ri = 0; ri < RPW; ++ri) { dcur[ri] = dnext[ri]; land(dcur[ri]); }
+            for (int ri = 0; ri < RPW; ++ri) { dcur[ri] = dnext[ri]; land(dcur[ri]); }
+        }
         if (r != rcur) {
             if (rcur >= 0) flush_row(rcur);
             rcur = r;
@@ -884,13 +897,15 @@ cnx_bwd_kernel(BwdArgs a) {
             if constexpr (MODE == 1) rs_dc = make_rsrc((const T*)a.dc1 + r * img, (uint32_t)(img * sizeof(T)));
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < t1)
-            hl.request(l.tile0_addr + (cur ^ 1) * (uint32_t)(Halo<T>::ELEMS * sizeof(T)), h0 + tnext.r * img, s, tnext.y0,
-                       tnext.x0, wave);
+        if (t + 1 < t1) {
+            hl.request(l.tile_addr(0, cur ^ 1), h0 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
+            if constexpr (MODE == 1) hl.request(l.tile_addr(1, cur ^ 1), doutp + tnext.r * img, s, tnext.y0, tnext.x0, wave);
+        }
         // (past the last tile this re-reads tile t's dout: the instruction count stays fixed)
-        load_dout(dnext, t + 1 < t1 ? tnext : tc);
+        if constexpr (MODE == 0) load_dout(dnext, t + 1 < t1 ? tnext : tc);
         __builtin_amdgcn_sched_barrier(0);
-        const T* tile = l.tile0 + cur * Halo<T>::ELEMS;
+        const T* tile = l.tile(0, cur);
+        const T* dotile = l.tile(MODE == 1 ? 1 : 0, cur);
         const bool border = tile_on_border(s, y0, x0);
 #pragma unroll 1
         for (int ri = 0; ri < RPW; ++ri) {
@@ -898,9 +913,13 @@ cnx_bwd_kernel(BwdArgs a) {
             const int gy = y0 + y;
             const bool ok = gy < s && gx < s;
             float dov[4];
-            unfrag(dcur[0], dov);
+            if constexpr (MODE == 0) {
+                unfrag(dcur[0], dov);
 #pragma unroll
-            for (int k = 0; k + 1 < RPW; ++k) dcur[k] = dcur[k + 1];   // rotate: static register indices
+                for (int k = 0; k + 1 < RPW; ++k) dcur[k] = dcur[k + 1];   // rotate: static register indices
+            } else {
+                ld4(dotile + Halo<T>::off(y + 1, m + 1, q), dov);          // zero outside the image
+            }
             RowFwd<T, false> f;
             chain_row<T, false, MODE == 1>(tile, nullptr, l.wc0, w, rw, border, gy, gx, s, y, q, m, lane, f);
             float dp1[4];
@@ -918,7 +937,7 @@ cnx_bwd_kernel(BwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { dqp[j][i] += dy[j][i] * f.g[j][i]; dbeta[j][i] += dy[j][i]; }
+                    for (int i = 0; i < 4; ++i) dqp[j][i] += dy[j][i] * f.g[j][i];
             } else {
                 // y, p1 (needed for dW_contract and d layer_scale)
                 float yv[2][4];
@@ -976,31 +995,37 @@ cnx_bwd_kernel(BwdArgs a) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_VMEM) : "memory");   // this wave's share of tile t+1 has landed
     }
     if (rcur >= 0) flush_row(rcur);
-    if constexpr (MODE == 0) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float v = red_m(dbeta[j][i]);
-                if (m == 0) atomicAdd(a.g.beta + 16 * j + 4 * q + i, v);
-            }
-    } else {
+    if constexpr (MODE == 1) {
+        // the four waves' partial sums meet in LDS (ds_add_f32), then one global atomic per element and workgroup
+        float* scratch = (float*)const_cast<T*>(l.tile(0, 0));   // con_w [32][16] | exp_w [16][32] | ls [16] | exp_b [32]
+        __syncthreads();                                          // every wave is past its last tile read
+        for (int i = threadIdx.x; i < 1024 + 48; i += NT) scratch[i] = 0.f;
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                atomicAdd(a.g.con_w + (16 * j + 4 * q + e) * 16 + m, aWp[j][e]);
-                atomicAdd(a.g.exp_w + (4 * q + e) * 32 + 16 * j + m, aWe[j][e]);
+                atomicAdd(scratch + (16 * j + 4 * q + e) * 16 + m, aWp[j][e]);
+                atomicAdd(scratch + 512 + (4 * q + e) * 32 + 16 * j + m, aWe[j][e]);
             }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float v1 = red_m(dls[i]);
-            if (m == 0) atomicAdd(a.g.ls + 4 * q + i, v1);
+            if (m == 0) atomicAdd(scratch + 1024 + 4 * q + i, v1);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float v = red_m(dbe[j][i]);
-                if (m == 0) atomicAdd(a.g.exp_b + 16 * j + 4 * q + i, v);
+                if (m == 0) atomicAdd(scratch + 1040 + 16 * j + 4 * q + i, v);
             }
+        }
+        __syncthreads();
+        if (!(a.dbg & 1)) {
+            for (int i = threadIdx.x; i < 512; i += NT) {
+                atomicAdd(a.g.con_w + i, scratch[i]);
+                atomicAdd(a.g.exp_w + i, scratch[512 + i]);
+            }
+            if (threadIdx.x < 16) atomicAdd(a.g.ls + threadIdx.x, scratch[1024 + threadIdx.x]);
+            else if (threadIdx.x < 48) atomicAdd(a.g.exp_b + threadIdx.x - 16, scratch[1024 + threadIdx.x]);
         }
     }
 }
@@ -1037,7 +1062,7 @@ cnx_bwd_conv_kernel(BwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, m = lane & 15;
-    Lds2<T> l = carve2<T>(smem, true, false, wave);   // tile0: h1 halo, tiled0: dc1 halo
+    Lds2<T> l = carve2<T>(smem, 3, false, wave);   // tile 0: h1 halo, tile 1: dc1 halo, tile 2: dout (+ the rho tile)
     const T* cw = (const T*)a.p.conv_w;  // [tap][ic][oc]
     frag_t wcT[9];  // A[row=ic][k=oc] of the transposed product dh2^T = Wc dc1^T
 #pragma unroll
@@ -1048,8 +1073,7 @@ cnx_bwd_conv_kernel(BwdArgs a) {
     const T* dc1 = (const T*)a.dc1_in;
     Halo<T> hl;
     hl.init(s, wave, lane);
-    constexpr int S_VMEM = 3 * RPW;   // dout + rho prefetch loads and dh0 stores issued after a DMA request
-    constexpr uint32_t TB = Halo<T>::ELEMS * sizeof(T);
+    constexpr int S_VMEM = RPW;   // dh0 stores issued after a DMA request (dout and 1/sigma arrive by DMA as well)
 
     int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
     int64_t t1 = t0 + a.geo.chunk < a.geo.total ? t0 + a.geo.chunk : a.geo.total;
@@ -1066,11 +1090,18 @@ cnx_bwd_conv_kernel(BwdArgs a) {
     { const float one = m < 9 ? 1.0f : 0.0f; make_frag(mk_int, one, one, one, one); }
     __amdgpu_buffer_rsrc_t rs_dh = make_rsrc(nullptr, 0);
 
-    auto flush_row = [&](int64_t r) {
+    // Gradient flushes: the four waves' partial sums meet in LDS first (ds_add_f32), then ONE global atomic per
+    // element and workgroup -- global fp32 atomics on a few hot addresses cost ~1 us per thousand.  `scratch` is
+    // a DMA buffer nothing is using at that point (see the call sites).
+    auto flush_row = [&](int64_t r, float* scratch) {
+        constexpr int NW = 9 * 256;
+        __syncthreads();
+        for (int i = threadIdx.x; i < NW + 32; i += NT) scratch[i] = 0.f;
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float v1 = red_m(dscp[i]), v2 = red_m(dshp[i]);
-            if (m == 0) { atomicAdd(a.dsc + r * 16 + 4 * q + i, v1); atomicAdd(a.dsh + r * 16 + 4 * q + i, v2); }
+            if (m == 0) { atomicAdd(scratch + NW + 4 * q + i, v1); atomicAdd(scratch + NW + 16 + 4 * q + i, v2); }
             dscp[i] = 0.f; dshp[i] = 0.f;
         }
 #pragma unroll
@@ -1078,33 +1109,35 @@ cnx_bwd_conv_kernel(BwdArgs a) {
             const float bt = __shfl(aB[t & 3], (t >> 2) * 16 + m);   // B[tap t][oc = m]
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                atomicAdd(a.g.conv_w + (t * 16 + 4 * q + e) * 16 + m, sc1[e] * aWc[t][e] + shr[e] * bt);
+                atomicAdd(scratch + (t * 16 + 4 * q + e) * 16 + m, sc1[e] * aWc[t][e] + shr[e] * bt);
             aWc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         aB = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        if (!(a.dbg & 1)) {
+            for (int i = threadIdx.x; i < NW; i += NT) atomicAdd(a.g.conv_w + i, scratch[i]);
+            if (threadIdx.x < 16) atomicAdd(a.dsc + r * 16 + threadIdx.x, scratch[NW + threadIdx.x]);
+            else if (threadIdx.x < 32) atomicAdd(a.dsh + r * 16 + threadIdx.x - 16, scratch[NW + threadIdx.x]);
+        }
+        __syncthreads();
     };
 
-    // centre-pixel dout and 1/sigma of this wave's rows, fetched one tile ahead (unconditional buffer loads)
-    auto load_centre = [&](frag_t d[RPW], float rr[RPW], const TileCoord& c) {
-        const __amdgpu_buffer_rsrc_t rs_d = make_rsrc((const T*)a.dout + c.r * img, (uint32_t)(img * sizeof(T)));
-        const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(a.rho + c.r * (int64_t)s * s, (uint32_t)((int64_t)s * s * 4));
-#pragma unroll
-        for (int ri = 0; ri < RPW; ++ri) {
-            const int gy = c.y0 + wave * RPW + ri, gxx = c.x0 + m;
-            const bool in = gy < s && gxx < s;
-            const int64_t pix = (int64_t)gy * s + gxx;
-            d[ri] = buf_ld_frag(rs_d, in ? (uint32_t)((pix * 16 + 4 * q) * sizeof(T)) : BUF_OOB, (const T*)nullptr);
-            rr[ri] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, in ? (uint32_t)(pix * 4) : BUF_OOB, 0, 0));
-        }
+    const T* doutp = (const T*)a.dout;
+    // 1/sigma of the tile's 16 x 16 pixels: one 4-byte LDS-DMA lane per pixel (pixel p = 64 wave + lane)
+    auto request_rho = [&](uint32_t dst, const TileCoord& c) {
+        const int pidx = wave * 64 + lane, gy = c.y0 + (pidx >> 4), gxx = c.x0 + (pidx & 15);
+        const float* gp = (gy < s && gxx < s) ? a.rho + (c.r * s + gy) * (int64_t)s + gxx : reinterpret_cast<const float*>(&g_zero16);
+        const uint32_t lds_addr = dst + wave * 256;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(gp), "s"(lds_addr) : "memory", "m0");
     };
-    frag_t dnext[RPW];
-    float rnext[RPW];
+    auto request_all = [&](int b, const TileCoord& c) {
+        hl.request(l.tile_addr(0, b), h0 + c.r * img, s, c.y0, c.x0, wave);
+        hl.request(l.tile_addr(1, b), dc1 + c.r * img, s, c.y0, c.x0, wave);
+        hl.request(l.tile_addr(2, b), doutp + c.r * img, s, c.y0, c.x0, wave);
+        request_rho(l.rho_addr + b * (uint32_t)(TH * TW * sizeof(float)), c);
+    };
     TileCoord tnext = tile_coord(a.geo, t0 < t1 ? t0 : 0);
-    if (t0 < t1) {
-        hl.request(l.tile0_addr, h0 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
-        hl.request(l.tiled0_addr, dc1 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
-        load_centre(dnext, rnext, tnext);
-    }
+    if (t0 < t1) request_all(0, tnext);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int64_t t = t0; t < t1; ++t) {
         const TileCoord tc = tnext;
@@ -1114,12 +1147,9 @@ cnx_bwd_conv_kernel(BwdArgs a) {
         const int gx = x0 + m;
         const int cur = (int)((t - t0) & 1);
         __syncthreads();
-        frag_t dcur[RPW];
-        float rcur4[RPW];
-#pragma unroll
-        for (int ri = 0; ri < RPW; ++ri) { dcur[ri] = dnext[ri]; rcur4[ri] = rnext[ri]; land(dcur[ri]); land(rcur4[ri]); }
         if (r != rcur) {
-            if (rcur >= 0) flush_row(rcur);
+            // (the other DMA buffer of tile 0 is idle here: tile t-1 is consumed, tile t+1 not yet requested)
+            if (rcur >= 0) flush_row(rcur, (float*)const_cast<T*>(l.tile(0, cur ^ 1)));
             rcur = r;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1131,14 +1161,12 @@ cnx_bwd_conv_kernel(BwdArgs a) {
             rs_dh = make_rsrc((const T*)a.dh0 + r * img, (uint32_t)(img * sizeof(T)));
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < t1) {
-            hl.request(l.tile0_addr + (cur ^ 1) * TB, h0 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
-            hl.request(l.tiled0_addr + (cur ^ 1) * TB, dc1 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
-        }
-        load_centre(dnext, rnext, t + 1 < t1 ? tnext : tc);
+        if (t + 1 < t1) request_all(cur ^ 1, tnext);
         __builtin_amdgcn_sched_barrier(0);
-        const T* tile = l.tile0 + cur * Halo<T>::ELEMS;
-        const T* dtile = l.tiled0 + cur * Halo<T>::ELEMS;
+        const T* tile = l.tile(0, cur);
+        const T* dtile = l.tile(1, cur);
+        const T* dotile = l.tile(2, cur);
+        const float* rtile = l.rho + cur * (TH * TW);
         const bool border = tile_on_border(s, y0, x0);
 #pragma unroll 1
         for (int ri = 0; ri < RPW; ++ri) {
@@ -1146,10 +1174,8 @@ cnx_bwd_conv_kernel(BwdArgs a) {
             const int gy = y0 + y;
             const bool ok = gy < s && gx < s;
             float dov[4];
-            unfrag(dcur[0], dov);
-            const float rho = rcur4[0];
-#pragma unroll
-            for (int k = 0; k + 1 < RPW; ++k) { dcur[k] = dcur[k + 1]; rcur4[k] = rcur4[k + 1]; }
+            ld4(dotile + Halo<T>::off(y + 1, m + 1, q), dov);   // zero outside the image
+            const float rho = rtile[y * TW + m];
             // dh2 = conv^T(dc1): h2[p] feeds c1[p - (i-1, j-1)] through K[i][j]
             f32x4 dh = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1202,14 +1228,34 @@ cnx_bwd_conv_kernel(BwdArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_VMEM) : "memory");   // this wave's share of tile t+1 has landed
     }
-    if (rcur >= 0) flush_row(rcur);
+    float* scratch = (float*)const_cast<T*>(l.tile(1, 0));   // (flush_row's first barrier: every wave is past its last dc1 read)
+    if (rcur >= 0) flush_row(rcur, scratch);
+    // con_b (16), conv_b (16), grn_beta (32): d con_b = ls * sum dout, d conv_b = sum dc1,
+    // d grn_beta[e] = sum_pixels dy[e] = sum_c Wp[e][c] (ls[c] sum_pixels dout[c])
+    if (threadIdx.x < 64) scratch[threadIdx.x] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float v1 = red_m(dsum[i]), v2 = red_m(dcsum[i]);
-        if (m == 0) {
-            atomicAdd(a.g.con_b + 4 * q + i, v1 * a.p.ls[4 * q + i]);
-            atomicAdd(a.g.conv_b + 4 * q + i, v2);
+        dsum[i] = v1 * a.p.ls[4 * q + i];    // this wave's sum of dp1[c], c = 4q + i (on every lane)
+        if (m == 0) { atomicAdd(scratch + 4 * q + i, dsum[i]); atomicAdd(scratch + 16 + 4 * q + i, v2); }
+    }
+    {
+        const T* pw = (const T*)a.p.con_w;   // [32][16]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc += St<T>::ld(pw + (16 * j + m) * 16 + 4 * q + i) * dsum[i];
+            acc = red_q(acc);
+            if (q == 0) atomicAdd(scratch + 32 + 16 * j + m, acc);
         }
+    }
+    __syncthreads();
+    if (!(a.dbg & 1)) {
+        if (threadIdx.x < 16) atomicAdd(a.g.con_b + threadIdx.x, scratch[threadIdx.x]);
+        else if (threadIdx.x < 32) atomicAdd(a.g.conv_b + threadIdx.x - 16, scratch[threadIdx.x]);
+        else if (threadIdx.x < 64) atomicAdd(a.g.beta + threadIdx.x - 32, scratch[threadIdx.x]);
     }
 }
 
@@ -1314,7 +1360,7 @@ inline int launch_k(K kern, int64_t grid, size_t lds, hipStream_t st, const A& a
 
 template <typename T>
 int fwd_launch(bool jvp, int mode, const FwdArgs& a, int64_t grid, hipStream_t st) {
-    const size_t lds = lds2_bytes<T>(jvp, false);
+    const size_t lds = lds2_bytes<T>(jvp ? 2 : 1, false);
     if (jvp) {
         if (mode == 0) return launch_k(cnx_fwd_kernel<T, true, 0>, grid, lds, st, a);
         return launch_k(cnx_fwd_kernel<T, true, 1>, grid, lds, st, a);
@@ -1384,45 +1430,47 @@ extern "C" int mfc_grn_bwd_finalize(int64_t R, const float* G, const float* dq, 
     return mfc_launch_status();
 }
 
+static const int BWD_DBG = getenv("MFC_CNX_BWD_DBG") ? atoi(getenv("MFC_CNX_BWD_DBG")) : 0;
+
 extern "C" int mfc_cnx_bwd_stats(int dtype, int64_t R, int s, const void* h0, const float* scale,
                                  const float* shift, const mfc_cnx_params* p, const float* q, const void* dout,
-                                 float* dq, float* dbeta, void* stream) {
-    if (!h0 || !scale || !shift || !params_ok(p) || !q || !dout || !dq || !dbeta) return MFC_EFAULT;
+                                 float* dq, void* stream) {
+    if (!h0 || !scale || !shift || !params_ok(p) || !q || !dout || !dq) return MFC_EFAULT;
     if (R <= 0 || s <= 0 || (dtype != MFC_F32 && dtype != MFC_BF16)) return MFC_EINVAL;
     if (s > MAX_S) return MFC_ENOSYS;
     BwdArgs a = {};
     int64_t grid;
     a.geo = make_geo(R, s, MAX_BLOCKS, grid);
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(nullptr);
-    a.g.beta = dbeta; a.q = q; a.dout = dout; a.dq = dq;
+    a.q = q; a.dout = dout; a.dq = dq; a.dbg = BWD_DBG;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFC_F32) return launch_k(cnx_bwd_kernel<float, 0>, grid, lds2_bytes<float>(false, false), st, a);
-    return launch_k(cnx_bwd_kernel<u16, 0>, grid, lds2_bytes<u16>(false, false), st, a);
+    if (dtype == MFC_F32) return launch_k(cnx_bwd_kernel<float, 0>, grid, lds2_bytes<float>(1, false), st, a);
+    return launch_k(cnx_bwd_kernel<u16, 0>, grid, lds2_bytes<u16>(1, false), st, a);
 }
 
 extern "C" int mfc_cnx_bwd_main(int dtype, int64_t R, int s, const void* h0, const float* scale,
                                 const float* shift, const mfc_cnx_params* p, const float* q, const float* kG,
                                 const void* dout, void* dc1, const mfc_cnx_grads* g, void* stream) {
     if (!h0 || !scale || !shift || !params_ok(p) || !q || !kG || !dout || !dc1 || !g) return MFC_EFAULT;
-    if (!g->con_w || !g->con_b || !g->ls || !g->exp_w || !g->exp_b || !g->conv_b) return MFC_EFAULT;
+    if (!g->con_w || !g->ls || !g->exp_w || !g->exp_b) return MFC_EFAULT;
     if (R <= 0 || s <= 0 || (dtype != MFC_F32 && dtype != MFC_BF16)) return MFC_EINVAL;
     if (s > MAX_S) return MFC_ENOSYS;
     BwdArgs a = {};
     int64_t grid;
     a.geo = make_geo(R, s, MAX_BLOCKS, grid);
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(g);
-    a.q = q; a.kG = kG; a.dout = dout; a.dc1 = dc1;
+    a.q = q; a.kG = kG; a.dout = dout; a.dc1 = dc1; a.dbg = BWD_DBG;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFC_F32) return launch_k(cnx_bwd_kernel<float, 1>, grid, lds2_bytes<float>(false, true), st, a);
-    return launch_k(cnx_bwd_kernel<u16, 1>, grid, lds2_bytes<u16>(false, true), st, a);
+    if (dtype == MFC_F32) return launch_k(cnx_bwd_kernel<float, 1>, grid, lds2_bytes<float>(2, true), st, a);
+    return launch_k(cnx_bwd_kernel<u16, 1>, grid, lds2_bytes<u16>(2, true), st, a);
 }
 
 extern "C" int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, const float* rho0,
                                 const float* scale, const float* shift, const mfc_cnx_params* p, const void* dc1,
                                 const void* dout, void* dh0, const mfc_cnx_grads* g, float* dscale, float* dshift,
                                 void* stream) {
-    if (!h0 || !rho0 || !scale || !shift || !params_ok(p) || !dc1 || !dout || !dh0 || !g || !g->conv_w || !dscale ||
-        !dshift)
+    if (!h0 || !rho0 || !scale || !shift || !params_ok(p) || !dc1 || !dout || !dh0 || !g || !g->conv_w || !g->conv_b ||
+        !g->con_b || !g->grn_beta || !dscale || !dshift)
         return MFC_EFAULT;
     if (R <= 0 || s <= 0 || (dtype != MFC_F32 && dtype != MFC_BF16)) return MFC_EINVAL;
     if (s > MAX_S) return MFC_ENOSYS;
@@ -1430,10 +1478,10 @@ extern "C" int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, con
     int64_t grid;
     a.geo = make_geo(R, s, MAX_BLOCKS, grid);
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(g);
-    a.rho = rho0; a.dc1_in = dc1; a.dout = dout; a.dh0 = dh0; a.dsc = dscale; a.dsh = dshift;
+    a.rho = rho0; a.dc1_in = dc1; a.dout = dout; a.dh0 = dh0; a.dsc = dscale; a.dsh = dshift; a.dbg = BWD_DBG;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFC_F32) return launch_k(cnx_bwd_conv_kernel<float>, grid, lds2_bytes<float>(true, false), st, a);
-    return launch_k(cnx_bwd_conv_kernel<u16>, grid, lds2_bytes<u16>(true, false), st, a);
+    if (dtype == MFC_F32) return launch_k(cnx_bwd_conv_kernel<float>, grid, lds2_bytes<float>(3, false), st, a);
+    return launch_k(cnx_bwd_conv_kernel<u16>, grid, lds2_bytes<u16>(3, false), st, a);
 }
 
 extern "C" int mfc_ln16_fwd(int dtype, int64_t n_pixels, const void* x, void* y, float* rstd, void* stream) {

@@ -160,7 +160,7 @@ def cnx_backward(h0, scale, shift, w: dict, s: int, G, q, dout, grads: dict, dh0
     dq = torch.zeros((R, 32), dtype=torch.float32, device=dev)
     kG = torch.empty_like(dq)
     _lib.check(L.mfc_cnx_bwd_stats(dt, R, s, h0.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctypes.byref(ps),
-                                   q.data_ptr(), dout.data_ptr(), dq.data_ptr(), grads["grn_beta"].data_ptr(), st),
+                                   q.data_ptr(), dout.data_ptr(), dq.data_ptr(), st),
                "mfc_cnx_bwd_stats")
     _lib.check(L.mfc_grn_bwd_finalize(R, G.data_ptr(), dq.data_ptr(), kG.data_ptr(),
                                       grads["grn_gamma"].data_ptr(), st), "mfc_grn_bwd_finalize")
