@@ -5,8 +5,9 @@
   (:62-67) and the falsy-``or`` defaults at :124-126.
 * ``create_flow_model(config, D)`` honours ``config.architecture`` (the reference's train_flow always
   builds the MLP flow, defect 1).
-* ``train_flow`` is the hot loop of trainers/train.py:330-345 only (tokenise -> train_step -> log);
-  workdir layout, checkpoints and plots are the "next" rows N1/N2 of SURVEY 8(f), not built yet.
+* ``train_flow`` is trainers/train.py:156-507: the hot loop (tokenise -> train_step -> log) plus, when a work
+  directory is given, the reference's workdir layout, checkpoints (trainers/checkpoint.py) and ``--resume``
+  (SURVEY 8(f) rows N1/N2).  The dataset front end (N4) is not built: batches come from ``data_iterator``.
 """
 from __future__ import annotations
 
@@ -88,12 +89,65 @@ def create_flow_model(config, noise_dimension: int, dtype=torch.float32):
     raise ValueError(f"Unknown architecture: {arch}")
 
 
-def train_flow(config, data_iterator, *, n_steps: int | None = None, dtype=torch.float32, device="cuda",
-               log_path: str | Path | None = None, reducer=None, rank: int = 0, world: int = 1):
-    """Hot loop of trainers/train.py:330-358 on this backend; ``data_iterator`` yields float32
-    ``[B, noise_dimension]`` host or device batches (the reference's iterator contract, :283-306)."""
+def synthetic_iterator(config, device="cuda", scale: float = 0.1):
+    """Endless ``[batch_size, noise_dimension]`` float32 batches ~ scale * N(0,1), seeded by ``config.seed`` (the
+    measurement input of SURVEY 8(d); the dataset front end is row N4 and not built)."""
+    g = torch.Generator(device=device).manual_seed(int(config.seed))
+    while True:
+        yield scale * torch.randn(config.batch_size, config.noise_dimension, generator=g, device=device)
+
+
+def _save_samples(samples_dir: Path, step: int, smps: torch.Tensor, config, original_dim: int) -> None:
+    """``samples/step_%04d.*`` (trainers/train.py:358-404): the first <= 16 samples as .npy and, when matplotlib is
+    importable, the reference's PNG grid (square images for MNIST, waveforms otherwise)."""
+    import numpy as np
+    n_show = min(16, len(smps))
+    arr = smps[:n_show].float().cpu().numpy()
+    np.save(samples_dir / f"step_{step:04d}.npy", arr)
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except Exception:   # noqa: BLE001
+        return
+    side = int(original_dim ** 0.5)
+    fig, axes = plt.subplots(4, 4, figsize=(8, 8))
+    for i, ax in enumerate(axes.ravel()):
+        ax.axis("off")
+        if i >= n_show:
+            continue
+        if (config.dataset or "mnist") == "mnist" and side * side == arr.shape[1]:
+            ax.imshow(arr[i].reshape(side, side), cmap="gray")
+        else:
+            ax.plot(arr[i][:4096], linewidth=0.5)
+    fig.savefig(samples_dir / f"step_{step:04d}.png", dpi=80)
+    plt.close(fig)
+
+
+def train_flow(config, data_iterator=None, *, resume: bool = False, n_steps: int | None = None,
+               dtype=torch.float32, device="cuda", log_path: str | Path | None = None, reducer=None,
+               rank: int = 0, world: int = 1, workdir: str | Path | None = None):
+    """``train_flow`` of trainers/train.py:156-507 on this backend.
+
+    ``data_iterator`` yields float32 ``[B, noise_dimension]`` host or device batches (the reference's iterator
+    contract, :283-306); without one ``config.data_dir`` must be set as in the reference (:168-173) -- and since the
+    dataset front end is not built, a set ``data_dir`` still raises ``NotImplementedError``.
+
+    With a work directory (``workdir`` argument or ``config.workdir``) rank 0 writes the reference's layout:
+    ``config.json``, ``metadata.json``, ``config_diff.json`` (on resume), ``logs/train_log.jsonl``,
+    ``samples/step_%04d.*`` every ``sample_every`` steps and at the end, ``checkpoints/step_%05d.msgpack`` + sidecar
+    at ``checkpoint_step`` (default: the last step) with ``max_checkpoints_to_keep`` cleanup, ``summary.json``.
+    ``resume=True`` continues from the newest checkpoint that loads (``load_checkpoint_and_resume``), else from
+    scratch, as the reference does (:259-270).  Returns ``(state, token_shape)``."""
+    from . import checkpoint as ck
     if config.condition_dimension % 2:
         raise ValueError(f"condition_dimension must be even, got {config.condition_dimension}")
+    if data_iterator is None:
+        if config.data_dir is None:
+            raise ValueError("config.data_dir must be provided. It cannot be None. "
+                             "Please specify a valid data directory path in your configuration.")
+        raise NotImplementedError("the dataset front end (datasets/audio.py, datasets/mnist.py) is not part of this "
+                                  "build: pass data_iterator (e.g. synthetic_iterator(config))")
     tokenization = create_tokenization_strategy(config)
     dataset = config.dataset or "mnist"
     if tokenization is not None:
@@ -101,16 +155,70 @@ def train_flow(config, data_iterator, *, n_steps: int | None = None, dtype=torch
         token_shape = compute_token_shape(tokenization, config.noise_dimension, dataset)
     else:
         D, token_shape = config.noise_dimension, None
+
+    wd = Path(workdir) if workdir is not None else (Path(config.workdir) if config.workdir is not None else None)
+    write = wd is not None and rank == 0
+    if write:
+        for sub in ("samples", "checkpoints", "logs"):
+            (wd / sub).mkdir(parents=True, exist_ok=True)
+        cfg_dict = json.loads(json.dumps(config.to_dict(), default=str))
+        if resume and (wd / "config.json").exists():
+            try:       # trainers/utils.py:1142-1163: a diff that cannot be computed is skipped, not fatal
+                from ..configs import diff_configs, load_config_from_json
+                diff = json.loads(json.dumps(diff_configs(load_config_from_json(wd / "config.json"), config), default=str))
+                for k in ("workdir",):
+                    diff["changed"].pop(k, None)
+                if diff["changed"] or diff["added"] or diff["removed"]:
+                    ck.save_json(wd / "config_diff.json", diff)
+            except (OSError, KeyError, TypeError, ValueError):
+                pass
+        commit, short = ck.get_git_commit_hash()
+        ck.save_json(wd / "metadata.json", {
+            "timestamp": __import__("datetime").datetime.now().isoformat(), "git_commit": commit,
+            "git_commit_short": short, "config_hash": ck.compute_config_hash(cfg_dict),
+            "python_version": __import__("sys").version.split()[0], "jax_version": None,
+            "backend": f"meanflow_audio_codec_amd (torch {torch.__version__})",
+            "platform": __import__("platform").platform(), "cpu_count": __import__("os").cpu_count(),
+            "device_info": {"device": torch.cuda.get_device_name(0) if torch.cuda.is_available() else "cpu",
+                            "world_size": world, "dtype": str(dtype)}})
+        ck.save_json(wd / "config.json", cfg_dict)
+
     model = create_flow_model(config, D, dtype=dtype)
     params = model.init(seed=config.seed, device=device)
     state = TrainState.create(apply_fn=model.apply, params=params,
                               tx=adamw(config.base_lr, config.weight_decay), model=model)
+    start_step = 0
+    if resume and wd is not None:
+        try:
+            state, start_step = ck.load_checkpoint_and_resume(wd, state, config)
+            print(f"Resuming from checkpoint at step {start_step}")
+        except (FileNotFoundError, ValueError) as e:
+            print(f"Failed to resume from checkpoint: {e}\nStarting from scratch")
+            start_step = 0
     strategy = create_loss_strategy(config)
-    key = PRNGKey(config.seed)
-    logf = open(log_path, "a") if log_path else None
+    key = PRNGKey(config.seed, start_step)     # the key is advanced once per completed step (training_steps.py)
+    if log_path is None and write:
+        log_path = wd / "logs" / "train_log.jsonl"
+    logger = ck.LogWriter(Path(log_path)) if (log_path and rank == 0) else None
     loss_avg = None
     steps = n_steps if n_steps is not None else config.n_steps
-    for step in range(steps):
+    checkpoint_step = config.checkpoint_step if config.checkpoint_step is not None else steps
+    saved_checkpoint = False
+    t_begin = time.time()
+    step_times = []
+
+    def draw_samples(step):
+        from ..evaluators.sampling import sample
+        B = config.batch_size
+        latents = torch.zeros(B, config.latent_dimension, dtype=torch.float32, device=device)   # train.py:360-364
+        smps = sample(state.apply_fn, D, state.work, PRNGKey(config.sample_seed), latents=latents,
+                      n_steps=config.sample_steps, use_improved_mean_flow=config.use_improved_mean_flow,
+                      guidance_scale=1.0)
+        if tokenization is not None and token_shape is not None:
+            smps = tokenization.detokenize(smps.float().reshape(B, token_shape[0], token_shape[1]))
+        _save_samples(wd / "samples", step, smps, config, config.noise_dimension)
+
+    for step in range(start_step, steps):
         t0 = time.time()
         x = torch.as_tensor(next(data_iterator), dtype=torch.float32).to(device)
         B = x.shape[0]
@@ -120,9 +228,34 @@ def train_flow(config, data_iterator, *, n_steps: int | None = None, dtype=torch
                                       global_batch=world * B)
         loss_val = float(loss)                         # device sync, as trainers/train.py:347
         loss_avg = loss_val if loss_avg is None else 0.99 * loss_avg + 0.01 * loss_val   # utils.ema :28-29
-        if logf:
-            logf.write(json.dumps({"step": step, "loss": loss_val, "loss_avg": loss_avg, "lr": config.base_lr,
-                                   "step_time": time.time() - t0}) + "\n")
-    if logf:
-        logf.close()
+        step_times.append(time.time() - t0)
+        if logger:
+            logger.write_step(step, {"loss": loss_val, "loss_avg": loss_avg, "lr": config.base_lr,
+                                     "step_time": step_times[-1]})
+        if step % 50 == 0 and rank == 0 and write:
+            print(f"step={step:04d} loss={loss_val:.9f} loss_avg={loss_avg:.9f}")
+        if write and step % config.sample_every == 0:
+            draw_samples(step)
+        if write and step + 1 == checkpoint_step:
+            ck.save_checkpoint_with_metadata(wd / "checkpoints" / f"step_{step + 1:05d}.msgpack", state, step + 1, config)
+            saved_checkpoint = True
+            if config.max_checkpoints_to_keep is not None:
+                ck.cleanup_old_checkpoints(wd, config.max_checkpoints_to_keep, keep_final=False, final_step=None)
+    if write:
+        draw_samples(steps)
+        if not saved_checkpoint:
+            ck.save_checkpoint_with_metadata(wd / "checkpoints" / f"step_{steps:05d}.msgpack", state, steps, config)
+        if config.max_checkpoints_to_keep is not None:
+            ck.cleanup_old_checkpoints(wd, config.max_checkpoints_to_keep, keep_final=True, final_step=steps)
+    if logger:
+        logger.close()
+    if write:
+        total = time.time() - t_begin
+        n = max(1, len(step_times))
+        ck.save_json(wd / "summary.json", {
+            "profiling": {"total_training_time_seconds": total, "total_training_time_hours": total / 3600.0,
+                          "steps_per_second": len(step_times) / total if total > 0 else 0.0,
+                          "avg_step_time": sum(step_times) / n,
+                          "param_count": int(sum(v.numel() for v in state.params.values()))},
+            "metrics": ck.generate_training_summary(wd / "logs" / "train_log.jsonl")})
     return state, token_shape
