@@ -421,6 +421,24 @@ def load_checkpoint(path: Path, state_template):
     return state_template
 
 
+def save_unwrapped_checkpoint(path: Path, params: dict) -> None:
+    """Parameters only (``trainers/utils.py:561-573``): ``serialization.to_bytes(params)`` of the nested tree."""
+    path = Path(path)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    with path.open("wb") as f:
+        write_tree(f, nest(params) if all(not isinstance(v, dict) for v in params.values()) else params)
+
+
+def load_unwrapped_checkpoint(path: Path, into: dict | None = None) -> dict:
+    """``trainers/utils.py:576-588``.  With ``into`` (flat ``{"blocks_0/...": tensor}``) the leaves are streamed
+    into those tensors -- e.g. a model's parameters for the 1-NFE decoder; without it the flat tree is returned."""
+    with Path(path).open("rb") as f:
+        if into is not None:
+            restore_into(f, dict(into))
+            return into
+        return flatten(read_tree(f))
+
+
 def get_checkpoint_metadata_path(checkpoint_path: Path) -> Path:
     return Path(checkpoint_path).with_suffix(".json")
 

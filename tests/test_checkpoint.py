@@ -148,3 +148,15 @@ def test_log_writer_and_summary(tmp_path):
     assert s["best_loss"] == {"value": pytest.approx(0.8), "step": 24} and s["logged_steps"] == 25
     assert s["convergence"]["improvement"] > 0 and s["loss_statistics"]["count"] == 25
     assert ck.generate_training_summary(tmp_path / "none.jsonl") == {"error": "No metrics found in log file"}
+
+
+def test_unwrapped_parameter_checkpoint(tmp_path):
+    st = _State(seed=3)
+    p = tmp_path / "params.msgpack"
+    ck.save_unwrapped_checkpoint(p, st.params)
+    assert p.read_bytes() == fm.msgpack_serialize(_np_tree(ck.nest(st.params)))
+    flat = ck.load_unwrapped_checkpoint(p)
+    assert set(flat) == set(st.params)
+    dst = {k: torch.zeros_like(v) for k, v in st.params.items()}
+    ck.load_unwrapped_checkpoint(p, into=dst)
+    assert all(torch.equal(dst[k], st.params[k]) for k in dst)
