@@ -110,12 +110,15 @@ def algorithmic_work(name, ints, nn):
 def symbol_of(name, ints, nn):
     """HIP kernel symbol (as rocprofv3 prints it, minus the namespace) of the main kernel behind one C-ABI call."""
     if name == "mfc_adamw":
-        return f"adamw_kernel<{'float' if ints[0] == 0 else 'unsigned short'}>"
+        T = "float" if ints[0] == 0 else "unsigned short"
+        return f"adamw_vec_kernel<{T}, false>" if ints[1] >= 4 else f"adamw_kernel<{T}>"
     if name == "mfc_gemm":
         dt, flags, M, N, K = ints[:5]
         T = "float" if dt == 0 else "unsigned short"
         tf = lambda b: "true" if b else "false"
-        return f"gemm_kernel<{T}, {32 if K <= 32 else 64}, {tf(flags & 1)}, {tf(flags & 2)}>"
+        if dt == 1 and not (flags & 3) and K == 128 and M <= 256 and not (flags & 8):
+            return f"gemm_nstream_kernel<{(((M + 15) // 16) + 3) // 4}>"   # 16-row tiles per wave
+        return f"gemm_kernel<{T}, {32 if K <= 32 else 64}, {tf(flags & 1)}, {tf(flags & 2)}, {128 if M > 64 else 64}>"
     if name.startswith("mfc_cnx_"):
         T = "float" if ints[0] == 0 else "unsigned short"
         if name in ("mfc_cnx_stats", "mfc_cnx_apply"):
@@ -131,7 +134,7 @@ def symbol_of(name, ints, nn):
 def measured_traffic(symbol):
     """average HBM bytes per launch of a kernel symbol from the committed rocprofv3 PMC passes, or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")) as f:
             tab = json.load(f)
         e = tab.get(symbol)
         return None if e is None else e["avg_hbm_bytes_per_launch"]

@@ -27,9 +27,10 @@ def test_algorithmic_bytes():
 
 def test_symbols_and_traffic_table():
     s = bench.symbol_of("mfc_adamw", (1, 802562048, 3), (True,) * 5)
-    assert s == "adamw_kernel<unsigned short>"
-    tab = json.loads((pathlib.Path(bench.ROOT) / "profiles" / "r01_pmc_traffic.json").read_text())
+    assert s == "adamw_vec_kernel<unsigned short, false>"
+    tab = json.loads((pathlib.Path(bench.ROOT) / "profiles" / "r01_final_pmc_traffic.json").read_text())
     assert s in tab and tab[s]["avg_hbm_bytes_per_launch"] > 1e9
     assert bench.measured_traffic(s) == tab[s]["avg_hbm_bytes_per_launch"]
     assert bench.symbol_of("mfc_cnx_bwd_main", (1, 128, 626), (True,) * 8) == "cnx_bwd_kernel<unsigned short, 1>"
-    assert bench.symbol_of("mfc_gemm", (0, 3, 4, 4, 16) + (0,) * 7, ()) == "gemm_kernel<float, 32, true, true>"
+    assert bench.symbol_of("mfc_gemm", (0, 3, 4, 4, 16) + (0,) * 7, ()) == "gemm_kernel<float, 32, true, true, 64>"
+    assert bench.symbol_of("mfc_gemm", (1, 16, 192, 6270016, 128) + (0,) * 7, ()) == "gemm_nstream_kernel<3>"
