@@ -390,6 +390,9 @@ def main():
         # per-kernel timing over the timed region (HIP events on the launch stream)
         rows = summarize_timing(records, args.steps)
         out["roofline"] = dominant_roofline(rows, ms_per_step, args.steps)
+        # the committed PMC table was collected on the literal bf16 workload at the default batch: null elsewhere
+        if out["roofline"] and not (args.workload == "literal" and args.dtype == "bf16" and B == WORKLOADS["literal"]["batch"]):
+            out["roofline"]["traffic"] = None
         out["sum_kernel_ms_per_step"] = round(sum(r["per_step_ms"] for r in rows), 2)
         out["launches_per_step"] = int(sum(r["launches"] for r in rows) / max(1, args.steps))
         out["top_kernels"] = [
