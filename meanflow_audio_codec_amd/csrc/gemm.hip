@@ -22,8 +22,9 @@ namespace {
 constexpr int BN = 128, GT = 256;   // BM is a template parameter (128, or 64 for remainder rows)
 constexpr int ldk_of(int BK, int es) { return BK + 16 / es; }   // K-contiguous tile [128][LDK]: +16 B pad
 constexpr int ldr_of(int es) { return es == 4 ? 132 : 144; }     // row-contiguous tile [BK][LDR]
-constexpr int tile_elems(int BK, int es) {
-    return 128 * ldk_of(BK, es) > BK * ldr_of(es) ? 128 * ldk_of(BK, es) : BK * ldr_of(es);
+constexpr int ldr_of_rows(int rows, int es) { return rows <= 128 ? ldr_of(es) : rows + 16; }   // [BK][rows + pad]
+constexpr int tile_elems(int BK, int es, int rows = 128) {
+    return rows * ldk_of(BK, es) > BK * ldr_of_rows(rows, es) ? rows * ldk_of(BK, es) : BK * ldr_of_rows(rows, es);
 }
 
 struct GemmArgs {
@@ -70,7 +71,7 @@ template <typename T, int BK, bool KC, int ROWS = 128> struct Stage {
     typedef typename Vec<T>::type vec_t;
     static constexpr int W = Vec<T>::W;
     static constexpr int LDK = ldk_of(BK, sizeof(T));
-    static constexpr int LDR = ldr_of(sizeof(T));
+    static constexpr int LDR = ldr_of_rows(ROWS, sizeof(T));
     static constexpr int TPR = BK / W, RPP = GT / TPR, NP = (ROWS + RPP - 1) / RPP;    // KC geometry
     static constexpr int TPK = ROWS / W, KPP = GT / TPK, NPT = (BK + KPP - 1) / KPP;  // !KC geometry
     static constexpr int NV = KC ? NP : NPT;                                          // vectors per thread
@@ -207,10 +208,10 @@ __global__ void __launch_bounds__(GT)
 gemm_kernel(GemmArgs g) {
     constexpr int MI = BMT / 32;          // 16-row MFMA tiles per wave along M (waves are 2 x 2)
     // operand tiles: [128][LDK] when the source is K-contiguous, [BK][LDR] when it is row-contiguous
-    constexpr int TE = tile_elems(BK, sizeof(T));
-    __shared__ __attribute__((aligned(16))) T lds[2 * TE];
+    constexpr int TEA = tile_elems(BK, sizeof(T), BMT > 128 ? BMT : 128), TE = tile_elems(BK, sizeof(T));
+    __shared__ __attribute__((aligned(16))) T lds[TEA + TE];
     T* As = lds;
-    T* Bs = lds + TE;
+    T* Bs = lds + TEA;
     typedef typename Frag<T>::type frag_t;
     typedef Stage<T, BK, !TA, BMT> SA;   // A: K-contiguous when not transposed ([M][K])
     typedef Stage<T, BK, TB> SB;    // B: K-contiguous when transposed ([N][K])
@@ -660,7 +661,11 @@ int launch(int flags, GemmArgs g, int bk, int splitk, int gelu, int64_t act_rows
     const int64_t M = g.M;
     const int64_t tail = M % 128;
     int rc = MFC_OK;
-    if (tail > 0 && tail <= 64) {
+    static const int bm192 = getenv("MFC_GEMM_BM192") ? atoi(getenv("MFC_GEMM_BM192")) : 1;
+    if (bm192 && M > 128 && M <= 192 && sizeof(T) == 2) {
+        // 128 + <= 64 row-stacked rows in ONE 192-row tile: the streamed operand is read once, not once per launch
+        rc = launch_rows<T, 192>(flags, g, bk, splitk, 0, M, st);
+    } else if (tail > 0 && tail <= 64) {
         if (M > tail) rc = launch_rows<T, 128>(flags, g, bk, splitk, 0, M - tail, st);
         if (!rc) rc = launch_rows<T, 64>(flags, g, bk, splitk, M - tail, tail, st);
     } else {
