@@ -361,7 +361,6 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     typedef u16 T;
     typedef Frag<T>::type frag_t;
     __shared__ __attribute__((aligned(16))) T Bs[NS_K * NS_LDR];
-    __shared__ __attribute__((aligned(16))) float slab[4][16 * 68];
     __shared__ __attribute__((aligned(16))) float bias_s[NS_BN];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -408,8 +407,11 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
         for (int p = 0; p < 4; ++p) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[p], 0, 0);
     };
 
-    float* cs = slab[wave];
-    const int lr = lane >> 2, lc = (lane & 3) * 16;
+    // The products are issued TRANSPOSED (C^T tile = B^T A^T: the weight tile is the MFMA A operand, the resident
+    // activation fragments the B operand) with the 16 rows of the n-tile j mapped to the columns
+    // 16 (rho >> 2) + 4 j + (rho & 3): lane (q, r) then ends up with C[row r][16 q .. 16 q + 15] of the 64-column
+    // tile in acc[.][j][e] -- a whole LayerNorm group and one 32-byte store per lane, with no LDS transpose.
+    const int lr = r, lc = 16 * q;
     const bool has_alpha = g.alpha != 1.0f;
     const __amdgpu_buffer_rsrc_t rs_bias = make_rsrc(g.bias, g.bias ? (uint32_t)(N * 4) : 0u);
     // Loop shape: the B tile of iteration t+1 is requested at the top of iteration t and committed to LDS at its
@@ -446,36 +448,30 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
             frag_t bf[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const T* bp = Bs + (16 * c + 4 * q + (r >> 2)) * NS_LDR + 16 * j + 4 * (r & 3);
+                // LDS transpose read: lane 4q'+p of group q supplies k-row 4q+q', columns 16p + 4j .. +3
+                const T* bp = Bs + (16 * c + 4 * q + (r >> 2)) * NS_LDR + 16 * (r & 3) + 4 * j;
                 bf[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mma16(acc[i][j], af[i][c], bf[j]);
+                for (int j = 0; j < 4; ++j) mma16(acc[i][j], bf[j], af[i][c]);
         }
         if (threadIdx.x < 16) *reinterpret_cast<u32x4*>(bias_s + 4 * threadIdx.x) = bias_v;
         __syncthreads();   // B tile consumed: the next iteration may overwrite it while slower waves are in the epilogue
 
-        // epilogue: 16 rows at a time through the wave's slab, one lane = 16 consecutive columns of a row
+        // epilogue: one lane = 16 consecutive columns of one row, straight from the accumulators
         uint32_t npr[8];       // the normalised primal of a (primal, tangent) tile pair, as stored (bf16 pairs)
         float rho_pr = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) npr[k] = 0u;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+            float v[16];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) cs[(4 * q + e) * 68 + 16 * j + r] = acc[i][j][e];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            float v[16];
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(cs + lr * 68 + lc + 4 * k4);
-                v[4 * k4] = t[0]; v[4 * k4 + 1] = t[1]; v[4 * k4 + 2] = t[2]; v[4 * k4 + 3] = t[3];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[i][j][e];
             // wave-uniform geometry of this 16-row tile (a wave without an i-th tile gets an empty resource)
             const int64_t row0 = 16 * (int64_t)(mt[i] < 0 ? 0 : mt[i]);
             const int64_t rows_valid = mt[i] < 0 ? 0 : (g.M - row0 < 16 ? g.M - row0 : 16);
