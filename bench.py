@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--decode-batch", type=int, default=None)
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (no roofline)")
     ap.add_argument("--no-overlap", action="store_true", help="reference order: loss -> all-reduce -> AdamW")
+    ap.add_argument("--no-fuse", action="store_true",
+                    help="single GPU: keep the big kernels' AdamW in its own launch instead of the weight-gradient GEMM's epilogue")
     ap.add_argument("--overlap", action="store_true",
                     help="per-block exchange + AdamW on a side stream during the reverse pass (default for --gpus > 1; "
                          "on one GPU it gains ~1%% and blurs the per-kernel timings, so it is off)")
@@ -76,6 +78,10 @@ def algorithmic_work(name, ints, nn):
         es = 4 if dt == 0 else 2
         has_res = nn[5] if len(nn) > 5 else False
         return es * (M * K + K * N + M * N * (2 if has_res else 1)), 2.0 * M * N * K, dt
+    if name == "mfc_gemm_adamw":
+        # weight gradient (bf16 operands) + AdamW epilogue: p, m, v read and written in fp32, bf16 copy written
+        flags, M, N, K = ints[:4]
+        return 2 * (M * K + K * N) + M * N * 26, 2.0 * M * N * K + 12.0 * M * N, 1
     if name.startswith("mfc_cnx_"):
         dt, R, s = ints[:3]
         es = 4 if dt == 0 else 2
@@ -112,6 +118,10 @@ def symbol_of(name, ints, nn):
     if name == "mfc_adamw":
         T = "float" if ints[0] == 0 else "unsigned short"
         return f"adamw_vec_kernel<{T}, false>" if ints[1] >= 4 else f"adamw_kernel<{T}>"
+    if name == "mfc_gemm_adamw":
+        flags, M, N, K = ints[:4]
+        tf = lambda b: "true" if b else "false"
+        return f"gemm_kernel<unsigned short, {32 if K <= 32 else 64}, {tf(flags & 1)}, {tf(flags & 2)}, {128 if M > 64 else 64}>"
     if name == "mfc_gemm":
         dt, flags, M, N, K = ints[:5]
         T = "float" if dt == 0 else "unsigned short"
@@ -143,6 +153,9 @@ def measured_traffic(symbol):
 
 
 def kernel_of(name, ints):
+    if name == "mfc_gemm_adamw":
+        flags, M, N, K = ints[:4]
+        return f"gemm_adamw_kernel<bf16,TA={flags & 1},TB={(flags >> 1) & 1}> M={M} N={N} K={K}"
     if name == "mfc_gemm":
         dt, flags, M, N, K = ints[:5]
         return f"gemm_kernel<{'f32' if dt == 0 else 'bf16'},TA={flags & 1},TB={(flags >> 1) & 1}> M={M} N={N} K={K}"
@@ -339,11 +352,12 @@ def main():
     key = PRNGKey(42)
 
     use_overlap = (world > 1 or args.overlap) and not args.no_overlap
+    use_fuse = world == 1 and not use_overlap and not args.no_fuse
 
     def one_step(state, key):
         tokens = tok.tokenize(clips)
         return train_step(state, key, tokens.reshape(B, -1), strat, reducer=reducer, row0=rank * B,
-                          global_batch=world * B, overlap=use_overlap)
+                          global_batch=world * B, overlap=use_overlap, fuse=use_fuse)
 
     def barrier():
         if world > 1:
@@ -383,7 +397,7 @@ def main():
                                f"(N={wl['window']}, hop={wl['hop']} -> D={D}), cond={wl['cond']}, latent={wl['latent']}, "
                                f"blocks={wl['blocks']}, {n_params / 1e9:.2f} B params, AdamW fp32 master",
                    "per_gpu_batch": B, "global_batch": world * B, "parallelism": f"dp{world}"},
-        "loss": loss_vals, "overlap_exchange_and_adamw": bool(use_overlap),
+        "loss": loss_vals, "overlap_exchange_and_adamw": bool(use_overlap), "fused_weight_gradient_adamw": bool(use_fuse),
     }
 
     if rank == 0:

@@ -104,6 +104,15 @@ int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
              float alpha, const void* R, int64_t ldr, float beta_res,
              int splitk, float* ws, float* ln_rstd, void* stream);
 
+/* Weight-gradient product with the AdamW update of that weight as its epilogue (single-GPU fast path: no gradient
+ * exchange between jax.value_and_grad and optax.adamw, trainers/training_steps.py:32-33):
+ *   g = grad_scale * op(A)[M,K] . op(B)[K,N]   (rounded to bf16, as the two-kernel path stores it)
+ *   m, v, p <- AdamW(g)  (mfc_adamw's arithmetic; fp32 [M,N] dense);  p_bf16[M,N] <- bf16(p)
+ * bf16 operands; N % 16 == 0 and 16-byte aligned buffers, else MFC_ENOSYS (use mfc_gemm + mfc_adamw). */
+int mfc_gemm_adamw(int flags, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                   int64_t ldb, float grad_scale, float* p, float* m, float* v, void* p_bf16, float lr,
+                   float b1, float b2, float eps, float wd, int64_t step, void* stream);
+
 /* ------------------------------------------------------------------ */
 /* ConvNeXt block interior (models/conv_flow.py:65-115,162-186)        */
 /* ------------------------------------------------------------------ */

@@ -311,16 +311,10 @@ template <typename TG>
 __global__ void adamw_kernel(int64_t n, float* p, u16* pw, const TG* g, float gscale, float* m, float* v,
                              float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
     for (int64_t o = blockIdx.x * (int64_t)ET + threadIdx.x; o < n; o += (int64_t)gridDim.x * ET) {
-        const float gv = St<TG>::ld(g + o) * gscale;
-        const float mm = b1 * m[o] + (1.0f - b1) * gv;
-        const float vv = b2 * v[o] + (1.0f - b2) * gv * gv;
-        m[o] = mm;
-        v[o] = vv;
-        const float pv = p[o];
-        const float upd = (mm / bc1) / (sqrtf(vv / bc2) + eps) + wd * pv;
-        const float np = pv - lr * upd;
-        p[o] = np;
-        if (pw) pw[o] = f32_to_bf16(np);
+        float pv = p[o], mv = m[o], vv = v[o];
+        adamw_elem(pv, mv, vv, St<TG>::ld(g + o) * gscale, lr, b1, b2, eps, wd, bc1, bc2);
+        p[o] = pv; m[o] = mv; v[o] = vv;
+        if (pw) pw[o] = f32_to_bf16(pv);
     }
 }
 
@@ -332,7 +326,6 @@ adamw_vec_kernel(int64_t n4, float* p, u16* pw, const TG* g, float gscale, float
                  float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-    const float ib1 = 1.0f / bc1, ib2 = 1.0f / bc2;
     for (int64_t o = blockIdx.x * (int64_t)ET + threadIdx.x; o < n4; o += (int64_t)gridDim.x * ET) {
         f4 gv;
         if constexpr (sizeof(TG) == 4) {
@@ -350,16 +343,13 @@ adamw_vec_kernel(int64_t n4, float* p, u16* pw, const TG* g, float gscale, float
         const f4 m0 = NT ? __builtin_nontemporal_load(mp) : *mp;
         const f4 v0 = NT ? __builtin_nontemporal_load(vp) : *vp;
         const f4 p0 = NT ? __builtin_nontemporal_load(pp) : *pp;
-        f4 mm, vv, np;
+        f4 mm = m0, vv = v0, np = p0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float gk = gv[k] * gscale;
-            mm[k] = b1 * m0[k] + (1.0f - b1) * gk;
-            vv[k] = b2 * v0[k] + (1.0f - b2) * gk * gk;
-            const float upd = (mm[k] / bc1) / (sqrtf(vv[k] / bc2) + eps) + wd * p0[k];
-            np[k] = p0[k] - lr * upd;
+            float pk = np[k], mk = mm[k], vk = vv[k];
+            adamw_elem(pk, mk, vk, gv[k] * gscale, lr, b1, b2, eps, wd, bc1, bc2);
+            np[k] = pk; mm[k] = mk; vv[k] = vk;
         }
-        (void)ib1; (void)ib2;
         if (NT) {
             __builtin_nontemporal_store(mm, mp);
             __builtin_nontemporal_store(vv, vp);

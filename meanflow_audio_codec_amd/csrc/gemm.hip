@@ -15,6 +15,7 @@
 // lane from K-contiguous LDS tiles, so one staging/addressing scheme serves
 // both.  fp32 accumulate always.
 #include "mfc_common.h"
+#include <cmath>
 #include <cstdlib>
 
 namespace {
@@ -43,6 +44,9 @@ struct GemmArgs {
     int m_fast;      // blockIdx.x walks M tiles (else N tiles)
     float* ln_rstd;  // MFC_GEMM_LN16: per-(row, 16-column group) 1/sigma, or null
     int64_t m_base;  // first row handled by this launch (rows below belong to another launch)
+    // mfc_gemm_adamw: the product is a weight gradient and the epilogue is the AdamW update of that weight
+    float* opt_p; float* opt_m; float* opt_v;   // fp32 master and moments, dense [M, N]; C = the bf16 working copy
+    float lr, b1, b2, eps, wd, bc1, bc2;
 };
 
 template <typename T> struct Vec;   // 16-byte global vector
@@ -178,6 +182,50 @@ __device__ inline void store_row16(const GemmArgs& g, int64_t row, int64_t col0,
     }
 }
 
+// AdamW on 16 consecutive elements of one row (same arithmetic, in the same order, as adamw_vec_kernel with a bf16
+// gradient: the accumulator is rounded to bf16 first so the fused and the two-kernel paths give identical bits);
+// on return v holds the new parameters (the caller stores them as the bf16 working copy)
+// v[4*k4 + k] is the gradient of column cb + 16*k4 + k of `row` (cb = 64-column base + 4 * (lane & 3)): in every one
+// of the four passes the 4 lanes of a row touch 64 contiguous bytes of p / m / v, so each load / store instruction of
+// the wave moves whole 64-byte pieces (a lane owning 16 consecutive columns would scatter 16-byte pieces 64 B apart).
+template <typename T, bool GUARD>
+__device__ inline void adamw_row_4x4(const GemmArgs& g, int64_t row, int64_t cb, float v[16]) {
+    const int64_t o = row * g.N + cb;
+    f32x4* pp = reinterpret_cast<f32x4*>(g.opt_p + o);      // + 4*k4 vectors = 16*k4 columns
+    f32x4* mp = reinterpret_cast<f32x4*>(g.opt_m + o);
+    f32x4* vp = reinterpret_cast<f32x4*>(g.opt_v + o);
+    f32x4 p0[4], m0[4], v0[4];
+    bool in[4];                           // N % 16 == 0: a 4-column group is inside the matrix or outside as a whole
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {      // all twelve loads in flight before the first store (which may alias, for all
+        in[k4] = !GUARD || cb + 16 * k4 < g.N;   // the compiler knows, and would serialise a load-update-store loop)
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        p0[k4] = in[k4] ? pp[4 * k4] : z;
+        m0[k4] = in[k4] ? mp[4 * k4] : z;
+        v0[k4] = in[k4] ? vp[4 * k4] : z;
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float pk = p0[k4][k], mk = m0[k4][k], vk = v0[k4][k];
+            adamw_elem(pk, mk, vk, bf16_to_f32(f32_to_bf16(v[4 * k4 + k])), g.lr, g.b1, g.b2, g.eps, g.wd, g.bc1, g.bc2);
+            p0[k4][k] = pk; m0[k4][k] = mk; v0[k4][k] = vk;
+        }
+    }
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    T* cp = (T*)g.C + row * g.ldc + cb;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+        if (!in[k4]) continue;
+        mp[4 * k4] = m0[k4];
+        vp[4 * k4] = v0[k4];
+        pp[4 * k4] = p0[k4];
+        if constexpr (sizeof(T) == 2)
+            *reinterpret_cast<u32x2*>(cp + 16 * k4) = u32x2{pack_bf16x2(p0[k4][0], p0[k4][1]), pack_bf16x2(p0[k4][2], p0[k4][3])};
+    }
+}
+
 // LayerNorm (no affine, eps 1e-6) over the 16 values of one pixel held by one lane
 __device__ inline float ln16_lane(float v[16]) {
     float sum = 0.f, sq = 0.f;
@@ -283,6 +331,22 @@ gemm_kernel(GemmArgs g) {
                 for (int e = 0; e < 4; ++e) cs[(4 * q + e) * CSS + 16 * j + r] = acc[i][j][e];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int64_t row = m0 + wm + 16 * i + lr;
+            if (g.opt_p) {    // mfc_gemm_adamw: the lane takes columns 4*(lane&3) + 16*k4 + (0..3), see adamw_row_4x4
+                const int64_t cb = n0 + wn + 4 * (lane & 3);
+                float gv[16];
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(cs + lr * CSS + 4 * (lane & 3) + 16 * k4);
+                    gv[4 * k4] = t[0] * g.alpha; gv[4 * k4 + 1] = t[1] * g.alpha; gv[4 * k4 + 2] = t[2] * g.alpha; gv[4 * k4 + 3] = t[3] * g.alpha;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (n0 + wn + 64 <= g.N) {        // wave-uniform: the whole 64-column strip is inside the matrix
+                    if (row < g.M) adamw_row_4x4<T, false>(g, row, cb, gv);
+                } else if (row < g.M && cb < g.N) {
+                    adamw_row_4x4<T, true>(g, row, cb, gv);
+                }
+                continue;
+            }
             const int64_t col0 = n0 + wn + lc;
             float v[16];
 #pragma unroll
@@ -693,12 +757,39 @@ inline int64_t ns_max_blocks() {
 
 }  // namespace
 
+namespace {
+struct OptArgs { float* p; float* m; float* v; float lr, b1, b2, eps, wd, bc1, bc2; };
+int gemm_impl(int dtype, int flags, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+              int64_t ldb, void* C, int64_t ldc, const float* bias, int64_t bias_rows, int64_t act_rows, float alpha,
+              const void* R, int64_t ldr, float beta_res, int splitk, float* ws, float* ln_rstd, const OptArgs* opt,
+              void* stream);
+}  // namespace
+
 extern "C" int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
                         const void* A, int64_t lda, const void* B, int64_t ldb,
                         void* C, int64_t ldc,
                         const float* bias, int64_t bias_rows, int64_t act_rows,
                         float alpha, const void* R, int64_t ldr, float beta_res,
                         int splitk, float* ws, float* ln_rstd, void* stream) {
+    return gemm_impl(dtype, flags, M, N, K, A, lda, B, ldb, C, ldc, bias, bias_rows, act_rows, alpha, R, ldr, beta_res,
+                     splitk, ws, ln_rstd, nullptr, stream);
+}
+
+extern "C" int mfc_gemm_adamw(int flags, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                              int64_t ldb, float grad_scale, float* p, float* m, float* v, void* p_bf16, float lr,
+                              float b1, float b2, float eps, float wd, int64_t step, void* stream) {
+    if (!p || !m || !v || !p_bf16) return MFC_EFAULT;
+    if (step < 1 || (flags & ~(MFC_GEMM_TRANS_A | MFC_GEMM_TRANS_B))) return MFC_EINVAL;
+    OptArgs o{p, m, v, lr, b1, b2, eps, wd, 1.0f - powf(b1, (float)step), 1.0f - powf(b2, (float)step)};
+    return gemm_impl(MFC_BF16, flags, M, N, K, A, lda, B, ldb, p_bf16, N, nullptr, 0, M, grad_scale, nullptr, 0, 0.f, 1,
+                     nullptr, nullptr, &o, stream);
+}
+
+namespace {
+int gemm_impl(int dtype, int flags, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+              int64_t ldb, void* C, int64_t ldc, const float* bias, int64_t bias_rows, int64_t act_rows, float alpha,
+              const void* R, int64_t ldr, float beta_res, int splitk, float* ws, float* ln_rstd, const OptArgs* opt,
+              void* stream) {
     if (!A || !B || !C) return MFC_EFAULT;
     if (M <= 0 || N <= 0 || K <= 0) return MFC_EINVAL;
     if (dtype != MFC_F32 && dtype != MFC_BF16) return MFC_EINVAL;
@@ -730,6 +821,14 @@ extern "C" int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
     g.vecB = (((ldb * es) % 16) == 0) && (((uintptr_t)B % 16) == 0);
     g.vecC = (N % 16 == 0) && ((ldc * es) % 16 == 0) && (((uintptr_t)C % 16) == 0) &&
              (!R || (((ldr * es) % 16 == 0) && (((uintptr_t)R % 16) == 0)));
+    g.opt_p = g.opt_m = g.opt_v = nullptr;
+    g.lr = g.b1 = g.b2 = g.eps = g.wd = g.bc1 = g.bc2 = 0.f;
+    if (opt) {
+        // the fused update lives in the row-contiguous epilogue of the tiled kernel
+        if (!g.vecC || use_ws || (((uintptr_t)opt->p | (uintptr_t)opt->m | (uintptr_t)opt->v) & 15)) return MFC_ENOSYS;
+        g.opt_p = opt->p; g.opt_m = opt->m; g.opt_v = opt->v;
+        g.lr = opt->lr; g.b1 = opt->b1; g.b2 = opt->b2; g.eps = opt->eps; g.wd = opt->wd; g.bc1 = opt->bc1; g.bc2 = opt->bc2;
+    }
     g.ln_rstd = nullptr;
     if (flags & MFC_GEMM_LN16) {
         if (!ln_rstd) return MFC_EFAULT;
@@ -740,7 +839,7 @@ extern "C" int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
     if (ln_tan && M - bias_rows > bias_rows) return MFC_EINVAL;
     g.m_base = 0;
     // skinny NN products with the whole A operand in registers
-    if (dtype == MFC_BF16 && !ta && !tb && K == NS_K && !use_ws && g.vecA && g.vecB && g.vecC && !ns_disabled() &&
+    if (dtype == MFC_BF16 && !opt && !ta && !tb && K == NS_K && !use_ws && g.vecA && g.vecB && g.vecC && !ns_disabled() &&
         ldb < (1 << 23) && ldc < (1 << 26) && (!R || ldr < (1 << 26)) && N < (1LL << 29)) {   // 32-bit buffer offsets
         NsPlan plan;
         const int mt = ns_make_plan(M, bias_rows, ln, ln_tan, plan);
@@ -775,3 +874,5 @@ extern "C" int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
     }
     return rc;
 }
+}  // namespace
+

@@ -108,4 +108,18 @@ static inline int mfc_launch_status() {
     return e == hipSuccess ? MFC_OK : MFC_EHIP;
 }
 
+// One AdamW element update (optax.adamw: m, v moments, bias correction bc = 1 - beta^step, decoupled weight decay).
+// Shared by mfc_adamw and the fused mfc_gemm_adamw epilogue; contraction is off so both evaluate the same
+// rounding sequence and stay bit-identical.
+__device__ inline void adamw_elem(float& p, float& m, float& v, float g, float lr, float b1, float b2, float eps,
+                                  float wd, float bc1, float bc2) {
+#pragma clang fp contract(off)
+    const float mm = b1 * m + (1.0f - b1) * g;
+    const float vv = b2 * v + (1.0f - b2) * g * g;
+    const float upd = (mm / bc1) / (sqrtf(vv / bc2) + eps) + wd * p;
+    p = p - lr * upd;
+    m = mm;
+    v = vv;
+}
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -231,11 +231,17 @@ class ConditionalConvFlow:
         pre = f"blocks_{i}/"
         return [k for k in self.param_shapes() if k.startswith(pre)]
 
-    def backward(self, w: dict, ctx: ConvCtx, dout: torch.Tensor, grads: dict, on_block=None):
+    def backward(self, w: dict, ctx: ConvCtx, dout: torch.Tensor, grads: dict, on_block=None, fused=None):
         """Reverse pass through the saved primal.  ``on_block(names)`` is called as soon as the gradients
         of one block are complete (lets the caller overlap the exchange / AdamW with the rest of the pass).  Writes every block parameter's gradient into
         ``grads`` (big kernels: overwritten in the model dtype; small fp32 leaves: overwritten too).
+        ``fused`` (train_state.FusedUpdater, single-GPU steps): the four big kernels of a block are updated by the
+        epilogue of their own weight-gradient product (``mfc_gemm_adamw``) and never appear in ``grads``; every
+        product that READS such a kernel is therefore issued before the one that updates it.
         Returns (dx [R,D], dcond [R,cond] fp32)."""
+        def dw(name, A, dY, alpha=1.0):
+            if fused is None or not fused.dw(name, A, dY, alpha):
+                dense_dw(A, dY, alpha=alpha, out=grads[name])
         R, K, S, s, T = ctx.R, self.num_blocks, self.S, self.spatial_size, self.dtype
         D, dev = self.noise_dimension, dout.device
         assert dout.shape == (R, D) and dout.dtype == T and dout.is_contiguous()
@@ -251,11 +257,11 @@ class ConditionalConvFlow:
             H0, O = ctx.H0[i * R:(i + 1) * R], ctx.O[i * R:(i + 1) * R]
             # out = (g2 W4 + b4)/K + x
             dg2 = dense_dx(dX, w[f"{b}/output_proj2/kernel"], alpha=1.0 / K)
-            dense_dw(g2, dX, alpha=1.0 / K, out=grads[f"{b}/output_proj2/kernel"])
+            dw(f"{b}/output_proj2/kernel", g2, dX, 1.0 / K)
             ops.colsum(dX, scale=1.0 / K, out=grads[f"{b}/output_proj2/bias"])
             da2 = ops.gelu_bwd(a2, dg2)
             dense_dx(da2, w[f"{b}/output_proj1/kernel"], out=dO)
-            dense_dw(O, da2, out=grads[f"{b}/output_proj1/kernel"])
+            dw(f"{b}/output_proj1/kernel", O, da2)
             ops.colsum(da2, out=grads[f"{b}/output_proj1/bias"])
             # ConvNeXt interior
             cg = self._cnx_g(grads, i)
@@ -269,12 +275,12 @@ class ConditionalConvFlow:
             dcond = dense_dx(dcp, w[f"{b}/conditioning_layer/kernel"], residual=dcond, beta=1.0)
             # h0 = g1 W2 + b2
             ops.colsum(dH0, out=grads[f"{b}/input_proj2/bias"])
-            dense_dw(g1, dH0, out=grads[f"{b}/input_proj2/kernel"])
             dg1 = dense_dx(dH0, w[f"{b}/input_proj2/kernel"])
+            dw(f"{b}/input_proj2/kernel", g1, dH0)
             da1 = ops.gelu_bwd(a1, dg1)
-            dense_dw(x_in, da1, out=grads[f"{b}/input_proj1/kernel"])
             ops.colsum(da1, out=grads[f"{b}/input_proj1/bias"])
             dX = dense_dx(da1, w[f"{b}/input_proj1/kernel"], residual=dX, beta=1.0)
+            dw(f"{b}/input_proj1/kernel", x_in, da1)
             if on_block is not None:
                 on_block(self._block_names[i])
         return dX, dcond, None

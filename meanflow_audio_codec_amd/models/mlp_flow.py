@@ -127,7 +127,7 @@ class ConditionalFlow:
             ops.copy2d(XC[R:, L:], outdot)
         return out, outdot, (ctx if save else None)
 
-    def backward(self, w: dict, ctx: MlpCtx, dout, grads: dict, on_block=None):
+    def backward(self, w: dict, ctx: MlpCtx, dout, grads: dict, on_block=None, fused=None):
         R, K, T = ctx.R, self.num_blocks, self.dtype
         D, L, I, dev = self.noise_dimension, self.latent_dimension, self.input_dimension, dout.device
         dXC = torch.zeros((R, I), dtype=T, device=dev)

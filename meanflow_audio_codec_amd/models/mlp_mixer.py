@@ -203,7 +203,7 @@ class ConditionalMLPMixerFlow:
             X = Xn
         return X[:R], (X[R:] if n_tan else None), (ctx if save else None)
 
-    def backward(self, w: dict, ctx: MixerCtx, dout, grads: dict, on_block=None):
+    def backward(self, w: dict, ctx: MixerCtx, dout, grads: dict, on_block=None, fused=None):
         R, K, nt, C = ctx.R, self.num_blocks, self.num_tokens, self.num_channels
         dX = dout
         dcond = torch.zeros((R, self.condition_dimension), dtype=torch.float32, device=dout.device)

@@ -79,6 +79,13 @@ class TrainState:
             self._grads = g
         return self._grads
 
+    def fused_updater(self, names=None):
+        """For a step opened with ``begin_update``: an object whose ``dw(name, A, dY, alpha)`` computes the weight
+        gradient ``A^T dY`` of leaf ``name`` and applies its AdamW update in the same kernel (``mfc_gemm_adamw``).
+        Only bf16-stored 2-D leaves with a 16-aligned second dimension qualify; for the others ``dw`` returns
+        False and the caller materialises the gradient as usual."""
+        return FusedUpdater(self, names)
+
     def begin_update(self):
         """Start one optimizer step whose leaves are updated piecewise with ``apply_subset``."""
         self.step += 1
@@ -101,3 +108,28 @@ class TrainState:
                       wd=tx.weight_decay, step=self.step, b1=tx.b1, b2=tx.b2, eps=tx.eps,
                       p_bf16=(w if w.dtype == torch.bfloat16 else None), grad_scale=grad_scale)
         return self
+
+
+class FusedUpdater:
+    def __init__(self, state: TrainState, names=None):
+        self.state = state
+        self.names = None if names is None else set(names)
+        self.done: set = set()
+
+    def wants(self, name: str) -> bool:
+        st = self.state
+        if self.names is not None and name not in self.names:
+            return False
+        w = st.work.get(name)
+        return (w is not None and w.dtype == torch.bfloat16 and w.dim() == 2 and w.shape[1] % 16 == 0
+                and name not in self.done)
+
+    def dw(self, name: str, A: torch.Tensor, dY: torch.Tensor, alpha: float = 1.0) -> bool:
+        if not self.wants(name) or A.dtype != torch.bfloat16 or dY.dtype != torch.bfloat16:
+            return False
+        st, tx = self.state, self.state.tx
+        ops.gemm_adamw(A, dY, trans_a=True, grad_scale=alpha, p=st.params[name], m=st.opt_state["mu"][name],
+                       v=st.opt_state["nu"][name], p_bf16=st.work[name], lr=tx.learning_rate, wd=tx.weight_decay,
+                       step=st.step, b1=tx.b1, b2=tx.b2, eps=tx.eps)
+        self.done.add(name)
+        return True

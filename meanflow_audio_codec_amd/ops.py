@@ -49,6 +49,26 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a=False, trans_b=False, bias
     return out
 
 
+def gemm_adamw(A, B, *, p, m, v, p_bf16, lr, wd, step, trans_a=False, trans_b=False, grad_scale=1.0, b1=0.9,
+               b2=0.999, eps=1e-8) -> None:
+    """Weight gradient op(A) op(B) fused with the AdamW update of that weight (``mfc_gemm_adamw``): updates the fp32
+    master ``p``, the moments ``m``/``v`` and the bf16 working copy ``p_bf16`` in place; bit-identical to
+    ``gemm(..., out=g_bf16)`` followed by ``adamw(p, g_bf16, ...)``."""
+    _lib.require_cuda(A, B)
+    assert A.dtype == B.dtype == torch.bfloat16 and A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
+    M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
+    K2, N = (B.shape[1], B.shape[0]) if trans_b else B.shape
+    assert K == K2, (A.shape, B.shape, trans_a, trans_b)
+    for t_ in (p, m, v):
+        assert t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == M * N
+    assert p_bf16.dtype == torch.bfloat16 and p_bf16.is_contiguous() and p_bf16.numel() == M * N
+    flags = (GEMM_TRANS_A if trans_a else 0) | (GEMM_TRANS_B if trans_b else 0)
+    rc = _lib.lib().mfc_gemm_adamw(flags, M, N, K, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), float(grad_scale),
+                                   p.data_ptr(), m.data_ptr(), v.data_ptr(), p_bf16.data_ptr(), float(lr), float(b1),
+                                   float(b2), float(eps), float(wd), int(step), _lib.stream_ptr())
+    _lib.check(rc, "mfc_gemm_adamw")
+
+
 # ---------------------------------------------------------------------------
 # ConvNeXt block interior
 # ---------------------------------------------------------------------------

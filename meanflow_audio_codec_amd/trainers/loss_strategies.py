@@ -70,7 +70,7 @@ class FlowMatchingLoss(LossStrategy):
         self.time_sampling = time_sampling or LogitNormalTimeSampling()
         self.use_weighted_loss = use_weighted_loss
 
-    def compute_loss(self, state, key, x, *, e=None, t=None, row0=0, global_batch=None, aux=None, on_block=None):
+    def compute_loss(self, state, key, x, *, e=None, t=None, row0=0, global_batch=None, aux=None, on_block=None, fused=None):
         model, w = state.model, state.work
         x = _prep_x(x)
         B = x.shape[0]
@@ -87,7 +87,7 @@ class FlowMatchingLoss(LossStrategy):
         pred, _, ctx = model.forward(w, z, cond, latents=latents, save=True, ctx=ctx_holder)
         loss, du, _ = ops.flow_loss(pred, target, kind=0, mode=_loss_mode(self.use_weighted_loss), Bglobal=Bg)
         grads = state.grad_buffers()
-        _, dcond, dlat = model.backward(w, ctx, du, grads, on_block=on_block)
+        _, dcond, dlat = model.backward(w, ctx, du, grads, on_block=on_block, fused=fused)
         model.backward_conditioning(w, ctx, dcond, latents, grads, dlat=dlat)
         if aux is not None:
             aux.update(pred=pred, t=t)
@@ -98,7 +98,7 @@ class _TwoTimeLoss(LossStrategy):
     kind = 0
 
     def _run(self, state, key, x, e, t, r, row0, global_batch, aux, *, nmin, nmax, mode, p, c, use_v_pass,
-             on_block=None):
+             on_block=None, fused=None):
         model, w = state.model, state.work
         x = _prep_x(x)
         B = x.shape[0]
@@ -134,7 +134,7 @@ class _TwoTimeLoss(LossStrategy):
         loss, du, _ = ops.flow_loss(u, target, dudt=dudt, n_tan=n_tan, t=t, r=r, kind=self.kind, mode=mode, p=p,
                                     c=c, Bglobal=Bg)
         grads = state.grad_buffers()
-        _, dcond, dlat = model.backward(w, ctx, du, grads, on_block=on_block)
+        _, dcond, dlat = model.backward(w, ctx, du, grads, on_block=on_block, fused=fused)
         model.backward_conditioning(w, ctx, dcond, latents, grads, dlat=dlat)
         if aux is not None:
             inv = None if perm is None else torch.argsort(perm)
@@ -156,9 +156,9 @@ class MeanFlowLoss(_TwoTimeLoss):
         self.c = c
 
     def compute_loss(self, state, key, x, *, e=None, t=None, r=None, row0=0, global_batch=None, aux=None,
-                     on_block=None):
+                     on_block=None, fused=None):
         return self._run(state, key, x, e, t, r, row0, global_batch, aux, nmin=0.0, nmax=1.0, mode=2,
-                         p=1.0 - self.gamma, c=self.c, use_v_pass=False, on_block=on_block)
+                         p=1.0 - self.gamma, c=self.c, use_v_pass=False, on_block=on_block, fused=fused)
 
 
 class ImprovedMeanFlowLoss(_TwoTimeLoss):
@@ -172,7 +172,7 @@ class ImprovedMeanFlowLoss(_TwoTimeLoss):
         self.use_weighted_loss = use_weighted_loss
 
     def compute_loss(self, state, key, x, *, e=None, t=None, r=None, row0=0, global_batch=None, aux=None,
-                     on_block=None):
+                     on_block=None, fused=None):
         ns = self.noise_schedule
         return self._run(state, key, x, e, t, r, row0, global_batch, aux, nmin=ns.noise_min, nmax=ns.noise_max,
-                         mode=_loss_mode(self.use_weighted_loss), p=1.0, c=1e-3, use_v_pass=True, on_block=on_block)
+                         mode=_loss_mode(self.use_weighted_loss), p=1.0, c=1e-3, use_v_pass=True, on_block=on_block, fused=fused)

@@ -7,6 +7,8 @@ Two schedules of the same arithmetic:
 
 * ``overlap=False``: the reference's order -- ``compute_loss`` then (gradient all-reduce) then
   ``apply_gradients`` (``trainers/training_steps.py:32-33``).
+* fused (the default without a reducer, i.e. on one GPU): the big kernels are updated inside their own weight-gradient
+  GEMM (``_fused_step``).
 * ``overlap=True`` (default): as soon as the reverse pass has finished one block, that block's gradients
   are (all-reduced over RCCL and) fed to the fused AdamW kernel on a SIDE HIP stream while the main
   stream continues the reverse pass of the earlier blocks.  AdamW is HBM-bound and the reverse-pass
@@ -31,8 +33,24 @@ def _side_stream(device):
     return s
 
 
+def _fused_step(state, key, x, loss_strategy, row0, global_batch):
+    """Single-GPU schedule: no gradient exchange sits between the reverse pass and the optimizer, so the big kernels
+    are updated by the epilogue of their own weight-gradient product (``mfc_gemm_adamw``: the bf16 gradient is never
+    written or re-read) and only the remaining leaves go through ``mfc_adamw``.  Bit-identical to the sequential
+    schedule."""
+    state.begin_update()
+    fused = state.fused_updater()
+    loss, grads = loss_strategy.compute_loss(state, key, x, row0=row0, global_batch=global_batch, fused=fused)
+    state.apply_subset([k for k in state.params if k not in fused.done], grads)
+    return state, loss, key.next()
+
+
 def _train_step_with_strategy(state, key, x, loss_strategy: LossStrategy, *, reducer=None, row0=0,
-                              global_batch=None, overlap=True):
+                              global_batch=None, overlap=True, fuse=None):
+    if fuse is None:
+        fuse = reducer is None and x.is_cuda
+    if fuse and reducer is None and x.is_cuda:
+        return _fused_step(state, key, x, loss_strategy, row0, global_batch)
     if not overlap or not x.is_cuda:
         loss, grads = loss_strategy.compute_loss(state, key, x, row0=row0, global_batch=global_batch)
         if reducer is not None:
@@ -68,8 +86,9 @@ def _train_step_with_strategy(state, key, x, loss_strategy: LossStrategy, *, red
 
 
 def train_step(state, key, x, loss_strategy: LossStrategy | None = None, *, reducer=None, row0=0,
-               global_batch=None, overlap=True):
+               global_batch=None, overlap=True, fuse=None):
+    """``fuse``: None = the fused single-GPU schedule whenever there is no reducer (``overlap`` then has no effect)."""
     if loss_strategy is None:
         loss_strategy = FlowMatchingLoss()
     return _train_step_with_strategy(state, key, x, loss_strategy, reducer=reducer, row0=row0,
-                                     global_batch=global_batch, overlap=overlap)
+                                     global_batch=global_batch, overlap=overlap, fuse=fuse)

@@ -177,7 +177,7 @@ def test_overlapped_train_step_matches_sequential():
         x, e, t, r = _draws(4, seed=22)
         key = PRNGKey(5)
         for _ in range(3):
-            state, loss, key = train_step(state, key, x.cuda(), ImprovedMeanFlowLoss(), overlap=overlap)
+            state, loss, key = train_step(state, key, x.cuda(), ImprovedMeanFlowLoss(), overlap=overlap, fuse=False)
         torch.cuda.synchronize()
         results.append(({k: v.clone() for k, v in state.params.items()}, loss.item(), state.step))
     (pa, la, sa), (pb, lb, sb) = results
@@ -185,3 +185,39 @@ def test_overlapped_train_step_matches_sequential():
     for k in pa:
         d = (pa[k] - pb[k]).abs()
         assert (d > 1e-5).float().mean().item() < 1e-3, (k, d.max().item())
+
+
+def test_fused_single_gpu_step_matches_sequential():
+    """The default single-GPU schedule (big kernels updated inside their weight-gradient GEMM, mfc_gemm_adamw) against
+    compute_loss -> apply_gradients from the same state: after one step the four big kernels of every block -- master,
+    both moments and the bf16 working copy -- are bit-identical (their gradients involve no atomics); the small leaves
+    agree up to the run-to-run noise of their fp32-atomic gradients.  Two more steps keep the runs together."""
+    from meanflow_audio_codec_amd.trainers import ImprovedMeanFlowLoss, PRNGKey, train_step
+    runs = []
+    for fuse in (False, True):
+        model, state, pq = _make(torch.bfloat16, seed=31)
+        x, e, t, r = _draws(4, seed=32)
+        key = PRNGKey(9)
+        state, loss, key = train_step(state, key, x.cuda(), ImprovedMeanFlowLoss(), overlap=False, fuse=fuse)
+        torch.cuda.synchronize()
+        snap = {k: (state.params[k].clone(), state.opt_state["mu"][k].clone(), state.opt_state["nu"][k].clone(),
+                    state.work[k].clone()) for k in state.params}
+        losses = [loss.item()]
+        for _ in range(2):
+            state, loss, key = train_step(state, key, x.cuda(), ImprovedMeanFlowLoss(), overlap=False, fuse=fuse)
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        runs.append((snap, losses, state))
+    (a, la, sa), (b, lb, sb) = runs
+    assert sa.step == sb.step == 3 and max(abs(u - v) for u, v in zip(la, lb)) < 1e-4
+    big = [k for k in a if k.endswith("_proj1/kernel") or k.endswith("_proj2/kernel")]
+    assert len(big) == 4 * model.num_blocks
+    for k in big:
+        assert a[k][3].dtype == torch.bfloat16
+        for u, v, what in zip(a[k], b[k], ("param", "mu", "nu", "bf16 copy")):
+            assert torch.equal(u, v), (k, what)
+    for k in a:
+        d = (a[k][0] - b[k][0]).abs()
+        assert (d > 1e-5).float().mean().item() < 1e-2, (k, d.max().item())
+    for k in sa.params:     # lr = 1e-3: after three steps the two runs are within a couple of updates of each other
+        assert (sa.params[k] - sb.params[k]).abs().max().item() < 3e-3, k

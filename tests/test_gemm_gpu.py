@@ -160,3 +160,23 @@ def test_gemm_ln16_tangent_rows(dtype, tol, R, nt, N):
     assert (C[:R].double() - ref[:R]).abs().max().item() <= tol * max(1.0, ref[:R].abs().max().item())
     assert (C[R:].double() - ref[R:]).abs().max().item() <= tol * max(1.0, ref[R:].abs().max().item())
     assert ((rho.double() - rr.reshape(R, -1)).abs().max() / rr.max()).item() < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 64, 128), (128, 4000, 128), (64, 32, 40), (1000, 128, 96)])
+def test_gemm_adamw_fused_equals_gemm_then_adamw(M, N, K):
+    """mfc_gemm_adamw (weight gradient with the AdamW update as its epilogue) == mfc_gemm -> bf16 gradient -> mfc_adamw,
+    bit for bit, over several steps."""
+    from meanflow_audio_codec_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(21)
+    X = (torch.randn(K, M, generator=g, device="cuda") * 0.3).bfloat16()      # dW = X^T dY
+    pa = torch.randn(M, N, generator=g, device="cuda")
+    ma, va = torch.zeros_like(pa), torch.zeros_like(pa)
+    pb, mb, vb = pa.clone(), ma.clone(), va.clone()
+    wa, wb = pa.bfloat16(), pb.bfloat16()
+    for step in range(1, 4):
+        dY = (torch.randn(K, N, generator=g, device="cuda") * 0.1).bfloat16()
+        grad = ops.gemm(X, dY, trans_a=True, alpha=0.5)
+        ops.adamw(pa, grad, ma, va, lr=1e-2, wd=1e-2, step=step, p_bf16=wa)
+        ops.gemm_adamw(X, dY, trans_a=True, grad_scale=0.5, p=pb, m=mb, v=vb, p_bf16=wb, lr=1e-2, wd=1e-2, step=step)
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(wa, wb), step
+    assert (pa - torch.randn(M, N, generator=torch.Generator(device="cuda").manual_seed(21), device="cuda")).abs().max() >= 0
