@@ -185,44 +185,47 @@ __device__ inline void store_row16(const GemmArgs& g, int64_t row, int64_t col0,
 // AdamW on 16 consecutive elements of one row (same arithmetic, in the same order, as adamw_vec_kernel with a bf16
 // gradient: the accumulator is rounded to bf16 first so the fused and the two-kernel paths give identical bits);
 // on return v holds the new parameters (the caller stores them as the bf16 working copy)
-// v[4*k4 + k] is the gradient of column cb + 16*k4 + k of `row` (cb = 64-column base + 4 * (lane & 3)): in every one
-// of the four passes the 4 lanes of a row touch 64 contiguous bytes of p / m / v, so each load / store instruction of
-// the wave moves whole 64-byte pieces (a lane owning 16 consecutive columns would scatter 16-byte pieces 64 B apart).
+// AdamW epilogue of one 16-row x 64-column wave tile: pass k4 handles rows 4*k4 + (lane >> 4), and the 16 lanes of a
+// row take 4 consecutive columns each, so every load / store instruction of the wave moves four 256-byte row
+// segments of p / m / v (a lane owning 16 consecutive columns would scatter 16-byte pieces 64 B apart, and the weights
+// whose rows are megabytes apart -- [128, S] -- want few, long segments).  gv[4*k4 + k]: gradient of row 4*k4 + (lane >> 4),
+// column 4 * (lane & 15) + k of the tile.
 template <typename T, bool GUARD>
-__device__ inline void adamw_row_4x4(const GemmArgs& g, int64_t row, int64_t cb, float v[16]) {
-    const int64_t o = row * g.N + cb;
-    f32x4* pp = reinterpret_cast<f32x4*>(g.opt_p + o);      // + 4*k4 vectors = 16*k4 columns
-    f32x4* mp = reinterpret_cast<f32x4*>(g.opt_m + o);
-    f32x4* vp = reinterpret_cast<f32x4*>(g.opt_v + o);
+__device__ inline void adamw_tile_16x64(const GemmArgs& g, int64_t row0, int64_t col0, int lane, float gv[16]) {
+    const int64_t cb = col0 + 4 * (lane & 15);
     f32x4 p0[4], m0[4], v0[4];
-    bool in[4];                           // N % 16 == 0: a 4-column group is inside the matrix or outside as a whole
+    bool in[4];
+    int64_t o[4];
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {      // all twelve loads in flight before the first store (which may alias, for all
-        in[k4] = !GUARD || cb + 16 * k4 < g.N;   // the compiler knows, and would serialise a load-update-store loop)
+        const int64_t row = row0 + 4 * k4 + (lane >> 4);   // the compiler knows, and would serialise a load-update-store loop)
+        o[k4] = row * g.N + cb;
+        in[k4] = !GUARD || (row < g.M && cb < g.N);
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-        p0[k4] = in[k4] ? pp[4 * k4] : z;
-        m0[k4] = in[k4] ? mp[4 * k4] : z;
-        v0[k4] = in[k4] ? vp[4 * k4] : z;
+        p0[k4] = in[k4] ? *reinterpret_cast<const f32x4*>(g.opt_p + o[k4]) : z;
+        m0[k4] = in[k4] ? *reinterpret_cast<const f32x4*>(g.opt_m + o[k4]) : z;
+        v0[k4] = in[k4] ? *reinterpret_cast<const f32x4*>(g.opt_v + o[k4]) : z;
     }
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float pk = p0[k4][k], mk = m0[k4][k], vk = v0[k4][k];
-            adamw_elem(pk, mk, vk, bf16_to_f32(f32_to_bf16(v[4 * k4 + k])), g.lr, g.b1, g.b2, g.eps, g.wd, g.bc1, g.bc2);
+            adamw_elem(pk, mk, vk, bf16_to_f32(f32_to_bf16(gv[4 * k4 + k])), g.lr, g.b1, g.b2, g.eps, g.wd, g.bc1, g.bc2);
             p0[k4][k] = pk; m0[k4][k] = mk; v0[k4][k] = vk;
         }
     }
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    T* cp = (T*)g.C + row * g.ldc + cb;
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
         if (!in[k4]) continue;
-        mp[4 * k4] = m0[k4];
-        vp[4 * k4] = v0[k4];
-        pp[4 * k4] = p0[k4];
-        if constexpr (sizeof(T) == 2)
-            *reinterpret_cast<u32x2*>(cp + 16 * k4) = u32x2{pack_bf16x2(p0[k4][0], p0[k4][1]), pack_bf16x2(p0[k4][2], p0[k4][3])};
+        *reinterpret_cast<f32x4*>(g.opt_m + o[k4]) = m0[k4];
+        *reinterpret_cast<f32x4*>(g.opt_v + o[k4]) = v0[k4];
+        *reinterpret_cast<f32x4*>(g.opt_p + o[k4]) = p0[k4];
+        if constexpr (sizeof(T) == 2) {
+            const int64_t row = row0 + 4 * k4 + (lane >> 4);
+            *reinterpret_cast<u32x2*>((T*)g.C + row * g.ldc + cb) = u32x2{pack_bf16x2(p0[k4][0], p0[k4][1]), pack_bf16x2(p0[k4][2], p0[k4][3])};
+        }
     }
 }
 
@@ -331,20 +334,17 @@ gemm_kernel(GemmArgs g) {
                 for (int e = 0; e < 4; ++e) cs[(4 * q + e) * CSS + 16 * j + r] = acc[i][j][e];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int64_t row = m0 + wm + 16 * i + lr;
-            if (g.opt_p) {    // mfc_gemm_adamw: the lane takes columns 4*(lane&3) + 16*k4 + (0..3), see adamw_row_4x4
-                const int64_t cb = n0 + wn + 4 * (lane & 3);
+            if (g.opt_p) {    // mfc_gemm_adamw: see adamw_tile_16x64 for the lane -> (row, column) mapping
                 float gv[16];
 #pragma unroll
                 for (int k4 = 0; k4 < 4; ++k4) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(cs + lr * CSS + 4 * (lane & 3) + 16 * k4);
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(cs + (4 * k4 + (lane >> 4)) * CSS + 4 * (lane & 15));
                     gv[4 * k4] = t[0] * g.alpha; gv[4 * k4 + 1] = t[1] * g.alpha; gv[4 * k4 + 2] = t[2] * g.alpha; gv[4 * k4 + 3] = t[3] * g.alpha;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (n0 + wn + 64 <= g.N) {        // wave-uniform: the whole 64-column strip is inside the matrix
-                    if (row < g.M) adamw_row_4x4<T, false>(g, row, cb, gv);
-                } else if (row < g.M && cb < g.N) {
-                    adamw_row_4x4<T, true>(g, row, cb, gv);
-                }
+                const int64_t row0 = m0 + wm + 16 * i, col0 = n0 + wn;
+                if (row0 + 16 <= g.M && col0 + 64 <= g.N) adamw_tile_16x64<T, false>(g, row0, col0, lane, gv);   // wave-uniform
+                else adamw_tile_16x64<T, true>(g, row0, col0, lane, gv);
                 continue;
             }
             const int64_t col0 = n0 + wn + lc;
