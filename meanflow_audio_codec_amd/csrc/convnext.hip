@@ -6,9 +6,10 @@
 //   y  = GRN(g1) = g1 (gamma + q) + beta                conv_flow.py:22-45
 //   o  = Conv1x1(y) [32->16] * layer_scale + h2         conv_flow.py:95-115
 //
-// The first LayerNorm is fused into the producing GEMM's epilogue (mfc_gemm MFC_GEMM_LN16, or the
-// standalone mfc_ln16_fwd): these kernels read h1 = LN_C(h0) and the per-pixel 1/sigma (rho0, only
-// needed by the tangent and by the reverse pass), so staging a tile is one FMA per element.
+// The first LayerNorm and its tangent come out of the producing GEMM's epilogue (mfc_gemm MFC_GEMM_LN16 /
+// MFC_GEMM_LN16T, or the standalone mfc_ln16_fwd / mfc_ln16_jvp): these kernels read h1 = LN_C(h0), its tangent and
+// (reverse pass only) the per-pixel 1/sigma rho0.  The FiLM modulation is folded into the conv weights per row r, so
+// a halo tile is a verbatim copy of h1 and arrives by LDS-DMA (see Halo below).
 // Data layout: NHWC maps [R, s, s, 16] in the storage dtype T (fp32 or bf16).
 // One workgroup = one 16x16 pixel tile (+1 halo) of one row r, 4 waves, each
 // wave owns 4 tile rows of 16 pixels = one MFMA M-tile.  Every per-pixel
@@ -27,8 +28,9 @@
 // apply pass), forward and backward.
 //
 // Workgroups are persistent over a contiguous range of tiles so weight-gradient
-// and per-row statistics accumulate in registers and are flushed with a few
-// atomics per workgroup (not per tile).
+// and per-row statistics accumulate in registers; they are reduced across the
+// workgroup's waves in LDS and flushed with one global atomic per element and
+// workgroup (hot-address fp32 atomics cost ~1 us per thousand).
 #include "mfc_common.h"
 #include <cstdlib>
 
@@ -102,10 +104,6 @@ template <typename T> __device__ inline void ld16(const T* p, float v[16]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) ld4(p + 4 * i, v + 4 * i);
 }
-template <typename T> __device__ inline void st16_lds(T* p, const float v[16]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) st4(p + 4 * i, v + 4 * i);
-}
 __device__ inline void frag_raw(f32x4& f, float a, float b, float c, float d) { f = f32x4{a, b, c, d}; }
 __device__ inline void frag_raw(s16x4& f, u16 a, u16 b, u16 c, u16 d) {
     f = s16x4{(short)a, (short)b, (short)c, (short)d};
@@ -167,127 +165,11 @@ inline Geo make_geo(int64_t R, int s, int64_t maxBlocks, int64_t& grid) {
     return g;
 }
 
-// ---- LDS carve --------------------------------------------------------------
-template <typename T> struct Lds {
-    T* h2s;      // [NHALO][CS]  h2 halo tile (zero outside the image)
-    T* aux;      // [NHALO][CS]  tangent halo (fwd JVP) or dc1 halo (bwd conv)
-    T* ws;       // per wave [6][16][CS]  weight-gradient transpose scratch (bwd main only)
-    float* fsc;  // [4][16] scale, shift, scaledot, shiftdot of the current row r
-};
-constexpr int WS_TILES = 6;
-template <typename T>
-__host__ __device__ inline size_t lds_bytes(bool aux, bool ws) {
-    size_t b = (size_t)NHALO * CS * sizeof(T) * (aux ? 2 : 1);
-    if (ws) b += (size_t)NWAVES * WS_TILES * 16 * CS * sizeof(T);
-    b = (b + 15) & ~(size_t)15;
-    return b + 64 * sizeof(float);
-}
-template <typename T>
-__device__ inline Lds<T> carve(unsigned char* base, bool aux, bool ws, int wave) {
-    Lds<T> l;
-    l.h2s = (T*)base;
-    l.aux = l.h2s + NHALO * CS;
-    T* w0 = l.h2s + (size_t)NHALO * CS * (aux ? 2 : 1);
-    l.ws = w0 + (size_t)wave * WS_TILES * 16 * CS;
-    size_t b = (size_t)NHALO * CS * sizeof(T) * (aux ? 2 : 1);
-    if (ws) b += (size_t)NWAVES * WS_TILES * 16 * CS * sizeof(T);
-    b = (b + 15) & ~(size_t)15;
-    l.fsc = (float*)(base + b);
-    return l;
-}
-
-// Halo staging, split so the global loads of tile t+1 fly while tile t computes:
-//   halo_load   : h1 = LN(h0) (and raw tangent h0dot + rho0) of the (TH+2)x(TW+2) halo -> registers
-//   halo_commit : h2 = FiLM(h1) (and its tangent) -> LDS, zero outside the image
+constexpr int WS_TILES = 6;   // y0, y1, dp1, n1, de0, de1: what the weight-gradient transposes of one tile row hold
 __device__ inline void unfrag(const f32x4& f, float v[4]) { v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3]; }
 __device__ inline void unfrag(const s16x4& f, float v[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = bf16_to_f32((u16)f[i]);
-}
-constexpr int HPT = (NHALO + NT - 1) / NT;  // halo pixels per thread (2)
-template <typename T, bool JVP> struct HaloRaw {
-    typename Frag<T>::type v[HPT][4], vd[JVP ? HPT : 1][4];
-    float rho[JVP ? HPT : 1];
-    unsigned ok;
-};
-template <typename T, bool JVP>
-__device__ inline void halo_load(HaloRaw<T, JVP>& h, const T* src, const T* srcd, const float* rho0, int64_t r,
-                                 int s, int y0, int x0) {
-    typedef typename Frag<T>::type frag_t;
-    h.ok = 0;
-#pragma unroll
-    for (int k = 0; k < HPT; ++k) {
-        const int hp = threadIdx.x + k * NT;
-        const int hy = hp / HW, hx = hp - hy * HW;
-        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-        if (hp < NHALO && gy >= 0 && gy < s && gx >= 0 && gx < s) {
-            h.ok |= 1u << k;
-            const int64_t off = ((r * s + gy) * (int64_t)s + gx) * 16;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                h.v[k][i] = *reinterpret_cast<const frag_t*>(src + off + 4 * i);
-                if constexpr (JVP) h.vd[k][i] = *reinterpret_cast<const frag_t*>(srcd + off + 4 * i);
-            }
-            if constexpr (JVP) h.rho[k] = rho0[(r * s + gy) * (int64_t)s + gx];
-        }
-    }
-}
-template <typename T, bool JVP>
-__device__ inline void halo_commit(const Lds<T>& l, const HaloRaw<T, JVP>& h) {
-#pragma unroll
-    for (int k = 0; k < HPT; ++k) {
-        const int hp = threadIdx.x + k * NT;
-        if (hp >= NHALO) continue;
-        float h2[16], h2d[16];
-        if (h.ok & (1u << k)) {
-            float h1[16];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) unfrag(h.v[k][i], h1 + 4 * i);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) h2[c] = (1.0f + l.fsc[c]) * h1[c] + l.fsc[16 + c];
-            if constexpr (JVP) {
-                // tangent of the fused LayerNorm: h1dot = rho0 (h0dot_c - h1 mean(h1 h0dot_c))
-                const float rho = h.rho[k];
-                float vd[16];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) unfrag(h.vd[k][i], vd + 4 * i);
-                float sd = 0.f;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) sd += vd[c];
-                const float md = sd * (1.0f / 16.0f);
-                float dot = 0.f;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) { vd[c] -= md; dot += h1[c] * vd[c]; }
-                dot *= (1.0f / 16.0f);
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const float h1d = rho * (vd[c] - h1[c] * dot);
-                    h2d[c] = l.fsc[32 + c] * h1[c] + (1.0f + l.fsc[c]) * h1d + l.fsc[48 + c];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) { h2[c] = 0.f; h2d[c] = 0.f; }
-        }
-        st16_lds<T>(l.h2s + hp * CS, h2);
-        if constexpr (JVP) st16_lds<T>(l.aux + hp * CS, h2d);
-    }
-}
-// plain copy of a halo (dc1) into the aux tile, zero outside the image
-template <typename T>
-__device__ inline void halo_commit_raw(T* dst, const HaloRaw<T, false>& h) {
-    typedef typename Frag<T>::type frag_t;
-#pragma unroll
-    for (int k = 0; k < HPT; ++k) {
-        const int hp = threadIdx.x + k * NT;
-        if (hp >= NHALO) continue;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            frag_t z;
-            frag_raw(z, (T)0, (T)0, (T)0, (T)0);
-            *reinterpret_cast<frag_t*>(dst + hp * CS + 4 * i) = (h.ok & (1u << k)) ? h.v[k][i] : z;
-        }
-    }
 }
 struct TileCoord { int64_t r; int y0, x0; };
 __device__ inline TileCoord tile_coord(const Geo& g, int64_t t) {
