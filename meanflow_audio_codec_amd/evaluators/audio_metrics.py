@@ -1,0 +1,51 @@
+"""Audio metrics that sit on the hot path's kernels -- SURVEY 8(f) row N3 (partial).
+
+``spectral_distance`` mirrors ``evaluators/audio_metrics.py:112-212`` for ``domain="mdct"``: the root-mean-square
+difference of the MDCT coefficients of reference and degraded signal, per sample, averaged over the batch.  Both
+transforms run through ``mfc_mdct_fwd`` and the squared-error reduction through ``mfc_flow_loss`` (one launch each).
+The reference evaluates in float64 on the host; here the arithmetic is fp32 on the device (tolerance in the test).
+``domain="mel"`` needs librosa, exactly as in the reference; the perceptual metrics (PESQ / STOI / ViSQOL,
+``audio_metrics.py:15-109``) are thin wrappers over third-party packages that are not part of this build.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..preprocessing.mdct import mdct
+
+
+def _as_device_2d(x, device):
+    t = torch.as_tensor(np.asarray(x, dtype=np.float32) if not isinstance(x, torch.Tensor) else x)
+    t = t.to(device=device, dtype=torch.float32)
+    return t.reshape(1, -1) if t.dim() == 1 else t
+
+
+def spectral_distance(reference, degraded, domain: str = "mdct", window_size: int = 512, hop_size: int | None = None,
+                      device: str = "cuda") -> float:
+    """Mean over the batch of ``sqrt(mean((MDCT(reference) - MDCT(degraded))**2))``; inputs ``[T]`` or ``[B, T]``
+    (numpy or torch)."""
+    ref_shape = tuple(np.shape(reference)) if not isinstance(reference, torch.Tensor) else tuple(reference.shape)
+    deg_shape = tuple(np.shape(degraded)) if not isinstance(degraded, torch.Tensor) else tuple(degraded.shape)
+    if ref_shape != deg_shape:
+        raise ValueError(f"Shape mismatch: reference {ref_shape} vs degraded {deg_shape}")
+    if domain == "mel":
+        try:
+            import librosa  # noqa: F401
+        except ImportError:
+            raise ImportError("librosa is required for mel-spectrogram computation. Install with: pip install librosa")
+        raise NotImplementedError("domain='mel' is not part of this build")
+    if domain != "mdct":
+        raise ValueError(f"Invalid domain: {domain}. Must be 'mdct' or 'mel'")
+    if len(ref_shape) not in (1, 2):
+        raise ValueError(f"expected [T] or [B, T], got {ref_shape}")
+    hop = window_size // 2 if hop_size is None else hop_size
+    r = _as_device_2d(reference, device)
+    d = _as_device_2d(degraded, device)
+    B = r.shape[0]
+    R = mdct(r, window_size=window_size, hop_size=hop).reshape(B, -1)
+    Dg = mdct(d, window_size=window_size, hop_size=hop).reshape(B, -1)
+    # per-example sum of squared differences (the weighted-L2 reduction without its weight or gradient)
+    _, _, pe = ops.flow_loss(Dg.contiguous(), R.contiguous(), kind=0, mode=0, want_grad=False)
+    return float(torch.sqrt(pe / R.shape[1]).mean().item())

@@ -116,3 +116,24 @@ def test_error_behaviour():
     X = mdct(torch.zeros(3, 2, 100).cuda(), config=cfg)
     assert X.shape == (3, 2, 11, 16)
     assert imdct(X, config=cfg).shape == (3, 2, 10 * 8 + 32)
+
+
+def test_spectral_distance_mdct_domain():
+    """evaluators/audio_metrics.py:112-170 (float64 on the host there): per-sample RMS difference of the MDCT
+    coefficients, batch mean -- GPU fp32 vs the float64 oracle transform."""
+    from meanflow_audio_codec_amd.evaluators import spectral_distance
+    rng = np.random.default_rng(7)
+    ref = rng.standard_normal((3, 8192)).astype(np.float32)
+    deg = (ref + 0.05 * rng.standard_normal(ref.shape)).astype(np.float32)
+    want = float(np.mean([np.sqrt(np.mean((o.mdct_f64(ref[i:i + 1], 512, 256).ravel()
+                                           - o.mdct_f64(deg[i:i + 1], 512, 256).ravel()) ** 2)) for i in range(3)]))
+    got = spectral_distance(ref, deg)
+    assert abs(got - want) <= 1e-4 * want, (got, want)
+    one = spectral_distance(ref[0], deg[0], window_size=256, hop_size=64)
+    w1 = float(np.sqrt(np.mean((o.mdct_f64(ref[:1], 256, 64).ravel() - o.mdct_f64(deg[:1], 256, 64).ravel()) ** 2)))
+    assert abs(one - w1) <= 1e-4 * w1
+    assert spectral_distance(ref, ref) == 0.0
+    with pytest.raises(ValueError, match="Shape mismatch"):
+        spectral_distance(ref, deg[:, :100])
+    with pytest.raises(ValueError, match="Invalid domain"):
+        spectral_distance(ref, deg, domain="stft")
