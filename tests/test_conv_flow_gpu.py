@@ -221,3 +221,41 @@ def test_fused_single_gpu_step_matches_sequential():
         assert (d > 1e-5).float().mean().item() < 1e-2, (k, d.max().item())
     for k in sa.params:     # lr = 1e-3: after three steps the two runs are within a couple of updates of each other
         assert (sa.params[k] - sb.params[k]).abs().max().item() < 3e-3, k
+
+
+def test_ci_shape_schedules_agree():
+    """SURVEY 8(d)'s CI shape (T = 16384 -> D = 32256, s = 179, S = 512656, 1.12 B parameters, bf16, B = 8): a size
+    where tiles are ragged, workgroups are persistent over many tiles, the K = D / K = S products are split-K (fp32
+    atomics: not bit-reproducible run to run) and the streamed operands exceed the caches.  Size-independent property:
+    the fused single-GPU schedule and compute_loss -> apply_gradients see the same loss and, after one step from the
+    same state, the same first moments (= 0.1 x the gradient) of all 32 big kernels up to the bf16 rounding of a
+    gradient element, and every parameter moved by at most one Adam step."""
+    from meanflow_audio_codec_amd.models import ConditionalConvFlow, TrainState, adamw
+    from meanflow_audio_codec_amd.preprocessing.tokenization import MDCTTokenization
+    from meanflow_audio_codec_amd.trainers import ImprovedMeanFlowLoss, PRNGKey, train_step
+    T, B, lr = 16384, 8, 1e-4
+    tok = MDCTTokenization(window_size=512, hop_size=256)
+    g = torch.Generator(device="cuda").manual_seed(42)
+    clips = 0.1 * torch.randn(B, T, generator=g, device="cuda")
+    x = tok.tokenize(clips).reshape(B, -1)
+    assert x.shape[1] == 32256
+    snaps, losses = [], []
+    for fuse in (False, True):
+        model = ConditionalConvFlow(32256, 128, 8, 256, dtype=torch.bfloat16)
+        state = TrainState.create(apply_fn=model.apply, params=model.init(seed=3), tx=adamw(lr, 1e-4), model=model)
+        p0 = {k: v.clone() for k, v in state.params.items() if k.endswith("_proj1/kernel") or k.endswith("_proj2/kernel")}
+        state, loss, _ = train_step(state, PRNGKey(42), x, ImprovedMeanFlowLoss(), overlap=False, fuse=fuse)
+        torch.cuda.synchronize()
+        losses.append(loss.item())
+        snaps.append({k: (state.opt_state["mu"][k], state.params[k], state.work[k]) for k in p0})
+        for k, v in p0.items():
+            step = (state.params[k] - v).abs().max().item()
+            assert 0 < step <= lr * 1.01 + 1e-4 * lr * v.abs().max().item() + 1e-7, (k, step)
+            assert torch.equal(state.work[k], state.params[k].bfloat16()), k
+        del state, model, p0
+    assert len(snaps[0]) == 32 and all(l == l and abs(l) < 1e6 for l in losses)
+    assert abs(losses[0] - losses[1]) <= 1e-5 * abs(losses[0])
+    for k in snaps[0]:
+        ma, mb = snaps[0][k][0], snaps[1][k][0]
+        scale = ma.abs().max().item()
+        assert scale > 0 and (ma - mb).abs().max().item() <= 1e-2 * scale, (k, (ma - mb).abs().max().item(), scale)
