@@ -73,8 +73,13 @@ def test_improved_mean_flow_loss_and_grads(dtype, tol, gtol):
     assert not bad, bad
     # reference property test/test_improved_mean_flow.py:31-54: t == r  =>  v_pred == u  (no tangent rows)
     aux2 = {}
-    ImprovedMeanFlowLoss().compute_loss(state, PRNGKey(0), x.cuda(), e=e.cuda(), t=t.cuda(), r=t.cuda(), aux=aux2)
+    loss2, _ = ImprovedMeanFlowLoss().compute_loss(state, PRNGKey(0), x.cuda(), e=e.cuda(), t=t.cuda(), r=t.cuda(), aux=aux2)
     assert aux2["n_tan"] == 0 and aux2["dudt"] is None
+    loss2_ref, _, aux2_ref = fo.imf_loss(fo.conv_flow_apply, fo.conv_flow_encode, pq, x.double(), e.double(), t.double(),
+                                         t.double())
+    assert torch.equal(aux2_ref["v_pred"], aux2_ref["u"])                       # the oracle has the property
+    assert _rel(aux2["u"], aux2_ref["v_pred"]) < tol                            # ... and the HIP path's v_pred IS its u
+    assert abs(loss2.item() - loss2_ref.item()) < tol * max(1.0, abs(loss2_ref.item()))
 
 
 def test_jvp_matches_reverse_mode_property():
