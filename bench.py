@@ -398,6 +398,7 @@ def main():
                                f"blocks={wl['blocks']}, {n_params / 1e9:.2f} B params, AdamW fp32 master",
                    "per_gpu_batch": B, "global_batch": world * B, "parallelism": f"dp{world}"},
         "loss": loss_vals, "overlap_exchange_and_adamw": bool(use_overlap), "fused_weight_gradient_adamw": bool(use_fuse),
+        "sharded_optimizer": bool(reducer is not None and getattr(reducer, "shard_optimizer", False)),
     }
 
     if rank == 0:

@@ -7,21 +7,110 @@ exchange is a plain SUM all-reduce of the gradient buffers between ``compute_los
 ``apply_gradients`` (trainers/training_steps.py:32-33 is where it slots in).  Big kernels are reduced
 in place tensor-by-tensor (each is its own multi-GB bucket, launched asynchronously so RCCL pipelines
 them); everything small is packed into one fp32 bucket.
+
+Sharded optimizer (``shard_optimizer=True``, the default for more than one rank): for the big bf16-stored kernels the
+all-reduce is split into its two halves around the optimizer -- reduce-scatter of the gradient, AdamW on this rank's
+1/world slice of (master, m, v), all-gather of the updated bf16 working copy.  Same bytes on the links as the
+all-reduce, but each GPU streams only 1/world of the 28 B/parameter optimizer traffic (57 of the 65 ms of ``mfc_adamw``
+at 8 GPUs).  A rank's fp32 master and moments are then authoritative only on its own slice; ``gather_master`` restores
+the full tensors everywhere (before a checkpoint).  gloo has no reduce-scatter: there the same slices are produced
+with an all-reduce and ``all_gather`` on views, so the CPU / single-GPU rehearsals run the same index arithmetic.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, group=None, small_numel: int = 1 << 20):
+    def __init__(self, group=None, small_numel: int = 1 << 20, shard_optimizer: bool | None = None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self.small_numel = small_numel
         self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
         self._flat = None
+        if shard_optimizer is None:
+            shard_optimizer = os.environ.get("MFC_SHARD_OPTIMIZER", "1") != "0"
+        self.shard_optimizer = bool(shard_optimizer) and self.world > 1
+        self._native = dist.get_backend(group) == "nccl"     # reduce_scatter_tensor / all_gather_into_tensor
+        self._tmp = {}
+        self.sharded: set = set()                            # leaves whose master / moments live in slices
+
+    # ---- sharded optimizer ------------------------------------------------------------------------------------
+    def _buf(self, key, n, dtype, device):
+        t = self._tmp.get(key)
+        if t is None or t.numel() != n or t.dtype != dtype or t.device != device:
+            t = torch.empty(n, dtype=dtype, device=device)
+            self._tmp[key] = t
+        return t
+
+    def _reduce_scatter(self, out: torch.Tensor, full: torch.Tensor) -> None:
+        """out <- this rank's slice of the SUM over ranks of ``full`` (flat, numel = world * out.numel())."""
+        if self._native:
+            try:
+                dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=self.group)
+                return
+            except (RuntimeError, AttributeError, NotImplementedError, ValueError, TypeError) as e:   # same arguments on every rank: all fall back
+                print(f"[mfc] reduce_scatter_tensor unavailable ({e}); using all_reduce", flush=True)
+                self._native = False
+        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
+        out.copy_(full[self.rank * out.numel():(self.rank + 1) * out.numel()])
+
+    def _all_gather(self, full: torch.Tensor, mine: torch.Tensor) -> None:
+        """full (flat) <- concatenation over ranks of ``mine``."""
+        if self._native:
+            try:
+                dist.all_gather_into_tensor(full, mine, group=self.group)
+                return
+            except (RuntimeError, AttributeError, NotImplementedError, ValueError, TypeError) as e:
+                print(f"[mfc] all_gather_into_tensor unavailable ({e}); using all_gather", flush=True)
+                self._native = False
+        n = mine.numel()
+        dist.all_gather([full[r * n:(r + 1) * n] for r in range(self.world)], mine, group=self.group)
+
+    def shardable(self, state, name: str, grad: torch.Tensor) -> bool:
+        w = state.work.get(name)
+        return (self.shard_optimizer and w is not None and w.dtype == torch.bfloat16 and grad.dtype == torch.bfloat16
+                and grad.is_contiguous() and w.is_contiguous() and grad.numel() > self.small_numel
+                and grad.numel() % (self.world * 64) == 0)
+
+    def sharded_update(self, state, names, grads: dict) -> list:
+        """One optimizer step (``state.step`` already advanced by ``begin_update``) of every shardable leaf in ``names``:
+        reduce-scatter the gradient, AdamW on the own slice, all-gather the bf16 working copy.  Returns the names that
+        were NOT handled (small / fp32 leaves: all-reduce + full AdamW, the caller's job)."""
+        from . import ops
+        rest = []
+        tx = state.tx
+        for k in names:
+            g = grads[k]
+            if not self.shardable(state, k, g):
+                rest.append(k)
+                continue
+            n = g.numel()
+            sh = n // self.world
+            lo = self.rank * sh
+            gsh = self._buf(("g", sh), sh, torch.bfloat16, g.device)
+            self._reduce_scatter(gsh, g.view(-1))
+            wsh = self._buf(("w", sh), sh, torch.bfloat16, g.device)
+            ops.adamw(state.params[k].view(-1)[lo:lo + sh], gsh, state.opt_state["mu"][k].view(-1)[lo:lo + sh],
+                      state.opt_state["nu"][k].view(-1)[lo:lo + sh], lr=tx.learning_rate, wd=tx.weight_decay,
+                      step=state.step, b1=tx.b1, b2=tx.b2, eps=tx.eps, p_bf16=wsh)
+            self._all_gather(state.work[k].view(-1), wsh)
+            self.sharded.add(k)
+        return rest
+
+    def gather_master(self, state) -> None:
+        """Make the fp32 master and both moments of every sharded leaf complete on every rank (checkpointing)."""
+        for k in sorted(self.sharded):
+            for t in (state.params[k], state.opt_state["mu"][k], state.opt_state["nu"][k]):
+                flat = t.view(-1)
+                sh = flat.numel() // self.world
+                mine = flat[self.rank * sh:(self.rank + 1) * sh].clone()
+                self._all_gather(flat, mine)
 
     def reduce_tensors(self, tensors) -> None:
         """SUM all-reduce a list of gradient tensors in place on the CURRENT stream (one block of the

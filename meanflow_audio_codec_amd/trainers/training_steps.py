@@ -53,6 +53,12 @@ def _train_step_with_strategy(state, key, x, loss_strategy: LossStrategy, *, red
         return _fused_step(state, key, x, loss_strategy, row0, global_batch)
     if not overlap or not x.is_cuda:
         loss, grads = loss_strategy.compute_loss(state, key, x, row0=row0, global_batch=global_batch)
+        if reducer is not None and reducer.shard_optimizer:
+            state.begin_update()
+            rest = reducer.sharded_update(state, list(state.params), grads)
+            loss = reducer.reduce({k: grads[k] for k in rest}, loss)
+            state.apply_subset(rest, grads)
+            return state, loss, key.next()
         if reducer is not None:
             loss = reducer.reduce(grads, loss)
         state = state.apply_gradients(grads=grads)
@@ -70,9 +76,12 @@ def _train_step_with_strategy(state, key, x, loss_strategy: LossStrategy, *, red
         ev.record(main)
         with torch.cuda.stream(side):
             side.wait_event(ev)
+            rest = names
             if reducer is not None:
-                reducer.reduce_tensors([grads_ref[n] for n in names])
-            state.apply_subset(names, grads_ref)
+                # big kernels: reduce-scatter -> AdamW on the own slice -> all-gather (distributed.py); the rest all-reduce
+                rest = reducer.sharded_update(state, names, grads_ref) if reducer.shard_optimizer else names
+                reducer.reduce_tensors([grads_ref[n] for n in rest])
+            state.apply_subset(rest, grads_ref)
         done.update(names)
 
     loss, grads = loss_strategy.compute_loss(state, key, x, row0=row0, global_batch=global_batch, on_block=on_block)

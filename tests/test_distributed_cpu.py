@@ -47,6 +47,16 @@ def _worker(rank, world, port, q):
         for k in blk:
             assert torch.equal(blk[k], grads[k]), k
         assert abs(red.reduce_scalar(loss).item() - total.item()) < 1e-6
+        # the two halves of the sharded optimizer's exchange (gloo: emulated with all_reduce / all_gather on views)
+        full = torch.arange(8 * world, dtype=torch.float32) * (rank + 1)
+        mine = torch.empty(8)
+        red._reduce_scatter(mine, full.clone())
+        want = torch.arange(8 * world, dtype=torch.float32)[rank * 8:(rank + 1) * 8] * sum(range(1, world + 1))
+        assert torch.equal(mine, want)
+        gathered = torch.zeros(8 * world)
+        red._all_gather(gathered, mine)
+        assert torch.equal(gathered, torch.arange(8 * world, dtype=torch.float32) * sum(range(1, world + 1)))
+        assert red.shard_optimizer and red.rank == rank and not red._native
         # second call reuses the flat bucket
         total2 = red.reduce({k: v.clone() for k, v in ref.items()}, loss)
         assert abs(total2.item() - total.item()) < 1e-6

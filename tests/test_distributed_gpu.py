@@ -1,0 +1,91 @@
+"""GPU, two ranks on one device over gloo: the data-parallel train step with the sharded optimizer (reduce-scatter ->
+AdamW on the own slice -> all-gather) against the plain all-reduce + full AdamW schedule."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, shard, overlap, steps=2):
+    from oracle import flow_oracle as fo
+    from meanflow_audio_codec_amd.distributed import GradReducer
+    from meanflow_audio_codec_amd.models import ConditionalConvFlow, TrainState, adamw
+    from meanflow_audio_codec_amd.trainers import ImprovedMeanFlowLoss, PRNGKey, train_step
+    D, CD, LAT, NB, B = 400, 128, 24, 2, 4
+    model = ConditionalConvFlow(D, CD, NB, LAT, dtype=torch.bfloat16)
+    p64 = fo.init_params(fo.conv_flow_shapes(D, CD, LAT, NB, latent_dim=LAT), seed=11)
+    flat = {k: v.float().cuda().contiguous() for k, v in fo.flatten(p64).items()}
+    state = TrainState.create(apply_fn=model.apply, params=flat, tx=adamw(1e-3, 1e-2), model=model)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(world * B, D, generator=g)[rank * B:(rank + 1) * B].cuda()
+    red = GradReducer(small_numel=1 << 12, shard_optimizer=shard)
+    key = PRNGKey(3)
+    for _ in range(steps):
+        state, loss, key = train_step(state, key, x, ImprovedMeanFlowLoss(), reducer=red, row0=rank * B,
+                                      global_batch=world * B, overlap=overlap)
+    torch.cuda.synchronize()
+    return state, red, loss.item()
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ref, _, loss_ref = _run(rank, world, shard=False, overlap=False)
+        for overlap in (False, True):
+            st, red, loss = _run(rank, world, shard=True, overlap=overlap)
+            big = sorted(red.sharded)
+            assert sum(k.startswith("blocks_") for k in big) == 8 and all(k.endswith("/kernel") for k in big), big
+            assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+            for k in st.work:       # what the kernels read agrees with the all-reduce schedule (atomic-order noise only)
+                d = (st.work[k].float() - ref.work[k].float()).abs()
+                assert d.max().item() < 5e-3 and (d > 1e-4).float().mean().item() < 0.05, (k, d.max().item())
+            # masters / moments are authoritative on the own slice only ...
+            k0 = big[0]
+            n = st.params[k0].numel() // world
+            own = slice(rank * n, (rank + 1) * n)
+            assert (st.opt_state["nu"][k0].view(-1)[own] > 0).any()
+            other = slice((1 - rank) * n, (2 - rank) * n)
+            assert not (st.opt_state["nu"][k0].view(-1)[other] > 0).any()
+            # ... until gather_master: then every rank holds the same, complete state, consistent with the bf16 copy
+            red.gather_master(st)
+            for k in big:
+                parts = [torch.empty_like(st.params[k]) for _ in range(world)]
+                dist.all_gather(parts, st.params[k])
+                assert torch.equal(parts[0], parts[1]), k
+                assert torch.equal(st.work[k], st.params[k].bfloat16()), k
+                assert (st.opt_state["nu"][k] > 0).float().mean().item() > 0.5
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_optimizer_two_ranks_one_gpu():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
