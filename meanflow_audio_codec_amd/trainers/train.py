@@ -236,11 +236,15 @@ def train_flow(config, data_iterator=None, *, resume: bool = False, n_steps: int
             print(f"step={step:04d} loss={loss_val:.9f} loss_avg={loss_avg:.9f}")
         if write and step % config.sample_every == 0:
             draw_samples(step)
+        if step + 1 == checkpoint_step and getattr(reducer, "shard_optimizer", False):
+            reducer.gather_master(state)      # collective: every rank (sharded masters / moments -> complete tensors)
         if write and step + 1 == checkpoint_step:
             ck.save_checkpoint_with_metadata(wd / "checkpoints" / f"step_{step + 1:05d}.msgpack", state, step + 1, config)
             saved_checkpoint = True
             if config.max_checkpoints_to_keep is not None:
                 ck.cleanup_old_checkpoints(wd, config.max_checkpoints_to_keep, keep_final=False, final_step=None)
+    if not (config.checkpoint_step is not None and config.checkpoint_step <= steps) and getattr(reducer, "shard_optimizer", False):
+        reducer.gather_master(state)          # the final checkpoint below needs the complete state, too
     if write:
         draw_samples(steps)
         if not saved_checkpoint:
