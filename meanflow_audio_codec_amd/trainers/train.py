@@ -243,8 +243,8 @@ def train_flow(config, data_iterator=None, *, resume: bool = False, n_steps: int
             saved_checkpoint = True
             if config.max_checkpoints_to_keep is not None:
                 ck.cleanup_old_checkpoints(wd, config.max_checkpoints_to_keep, keep_final=False, final_step=None)
-    if not (config.checkpoint_step is not None and config.checkpoint_step <= steps) and getattr(reducer, "shard_optimizer", False):
-        reducer.gather_master(state)          # the final checkpoint below needs the complete state, too
+    if getattr(reducer, "shard_optimizer", False):
+        reducer.gather_master(state)          # the final checkpoint below (and the caller) get the complete state
     if write:
         draw_samples(steps)
         if not saved_checkpoint:
