@@ -270,6 +270,20 @@ template <typename T> struct Halo {
     }
 };
 
+// bf16 only: two conv taps per MFMA.  v_mfma_f32_16x16x32_bf16 contracts k = 32: lane (q, r) holds k = 8q .. 8q+7 of
+// row / column r, so lanes q < 2 carry the 16 input channels of tap 2p and lanes q >= 2 those of tap 2p+1 (one 16-byte
+// chunk of the halo pixel each).  Same MFMA cycles as two K16 steps, but half the instructions and half the time the
+// MFMA holds the SIMD's issue port -- which is what these VALU-issue-bound kernels are short of.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ inline void mma32(f32x4& acc, const s16x8& a, const s16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+__device__ inline s16x8 pack8(const float v[8]) {
+    typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(s16x8, u32x4_{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                            pack_bf16x2(v[6], v[7])});
+}
+
 // vmcnt note.  vmcnt is one in-order counter over loads, stores and LDS-DMA.  The DMA for tile t+1 is
 // requested at the top of tile t and awaited at its bottom with s_waitcnt vmcnt(S), S = the number of
 // VMEM instructions this wave issues in between.  For S to be a compile-time constant those
@@ -317,7 +331,14 @@ template <typename T> struct FwdW {
     typedef typename Frag<T>::type frag_t;
     frag_t we[2], wp[2];
     float bc[4], be[2][4], bp[4], ls[4], gam[2][4], bet[2][4];
+    int xo[5];   // bf16: element offset (within a tile row band) of this lane's 16-byte chunk for the tap pairs (2p, 2p+1);
+                 // the fifth "pair" is tap 8 alone (its upper 16 k carry zero weights)
     __device__ inline void load(const Dev& d, int q, int m) {
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const int t = pr < 4 ? 2 * pr + (q >> 1) : 8, dy = t / 3, dx = t - 3 * dy;
+            xo[pr] = ((dy * Halo<T>::CPP + (q & 1)) * HW + m + dx) * Halo<T>::EPC;
+        }
         const T* ew = (const T*)d.exp_w;  // [16][32]
         we[0] = load_bfrag<T>(ew, 32, 1, 0, 0, q, m);
         we[1] = load_bfrag<T>(ew, 32, 1, 0, 16, q, m);
@@ -355,10 +376,13 @@ __device__ inline void stash_conv_w(T* wc0, const Dev& d, int q, int m, int lane
 }
 
 // The row-r dependent part: FiLM folded into the conv.
-template <typename T, bool JVP> struct RowW {
+// K32W: the conv taps as K = 32 steps (bf16 only; pays where the MFMA count is highest -- the forward JVP kernels)
+template <typename T, bool JVP, bool K32W = false> struct RowW {
     typedef typename Frag<T>::type frag_t;
-    frag_t wc[9];               // diag(1 + scale) Wc
+    static constexpr bool K32 = K32W && sizeof(T) == 2;
+    frag_t wc[9];               // diag(1 + scale) Wc   (bf16: only tap 8 is used, the others live in w2)
     frag_t wcd[JVP ? 9 : 1];    // diag(scaledot) Wc
+    s16x8 w2[K32 ? 5 : 1], w2d[(K32 && JVP) ? 5 : 1];   // bf16: the tap pairs (2p, 2p+1) and (8, -) as K = 32 A operands
     f32x4 b, bd;                // bc + sum_taps Wc^T shift (interior tiles) and its tangent
     frag_t shf, shdf;           // shift / shiftdot as a B operand (border tiles mask it per tap)
     float sc1[4], sh[4];        // 1 + scale, shift of channels 4q..4q+3 (FiLM of the centre pixel)
@@ -382,11 +406,38 @@ template <typename T, bool JVP> struct RowW {
             const frag_t w0 = *reinterpret_cast<const frag_t*>(wc0 + (t * 64 + lane) * 4);
             float wv[4];
             unfrag(w0, wv);
-            make_frag(wc[t], wv[0] * sc1[0], wv[1] * sc1[1], wv[2] * sc1[2], wv[3] * sc1[3]);
+            if (!K32) make_frag(wc[t], wv[0] * sc1[0], wv[1] * sc1[1], wv[2] * sc1[2], wv[3] * sc1[3]);
             mma16(b, w0, shf);
             if constexpr (JVP) {
-                make_frag(wcd[t], wv[0] * scd4[0], wv[1] * scd4[1], wv[2] * scd4[2], wv[3] * scd4[3]);
+                if (!K32) make_frag(wcd[t], wv[0] * scd4[0], wv[1] * scd4[1], wv[2] * scd4[2], wv[3] * scd4[3]);
                 mma16(bd, w0, shdf);
+            }
+        }
+        if constexpr (K32) {
+            // lane (q, m) of pair p: tap 2p + (q >> 1), input channels 8 (q & 1) .. +7, output channel m -- two of the
+            // stashed K16 fragments (lane groups 2 (q & 1) and 2 (q & 1) + 1 of that tap, same m)
+            const int m = lane & 15, h = q & 1;
+            float s8[8], sd8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s8[i] = 1.0f + sc[r * 16 + 8 * h + i];
+                sd8[i] = JVP ? scd[r * 16 + 8 * h + i] : 0.f;
+            }
+#pragma unroll
+            for (int pr = 0; pr < 5; ++pr) {
+                const int t = pr < 4 ? 2 * pr + (q >> 1) : 8;
+                const float live = (pr < 4 || q < 2) ? 1.0f : 0.0f;
+                float wv[8], a8[8];
+                unfrag(*reinterpret_cast<const frag_t*>(wc0 + (t * 64 + (2 * h) * 16 + m) * 4), wv);
+                unfrag(*reinterpret_cast<const frag_t*>(wc0 + (t * 64 + (2 * h + 1) * 16 + m) * 4), wv + 4);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a8[i] = wv[i] * s8[i] * live;
+                w2[pr] = pack8(a8);
+                if constexpr (JVP) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) a8[i] = wv[i] * sd8[i] * live;
+                    w2d[pr] = pack8(a8);
+                }
             }
         }
     }
@@ -403,8 +454,8 @@ template <typename T, bool JVP> struct RowFwd {
 };
 
 // tile / tiled: dense halo of h1 / its tangent.  border: the tile touches the image edge (uniform).
-template <typename T, bool JVP, bool WG>
-__device__ inline void chain_row(const T* tile, const T* tiled, const T* wc0, const FwdW<T>& w, const RowW<T, JVP>& rw,
+template <typename T, bool JVP, bool WG, bool K32W = false>
+__device__ inline void chain_row(const T* tile, const T* tiled, const T* wc0, const FwdW<T>& w, const RowW<T, JVP, K32W>& rw,
                                  bool border, int gy, int gx, int s, int y, int q, int m, int lane, RowFwd<T, JVP>& o) {
     typedef typename Frag<T>::type frag_t;
     f32x4 acc = rw.b, accd = rw.bd;
@@ -423,20 +474,39 @@ __device__ inline void chain_row(const T* tile, const T* tiled, const T* wc0, co
                 mma16(acc, w0, in ? rw.shf : z);
                 if constexpr (JVP) mma16(accd, w0, in ? rw.shdf : z);
             }
+        // The K = 32 steps below continue these accumulators.  hipcc (ROCm 7.2) does not separate dependent MFMAs of
+        // different shapes correctly: a 16x16x32 result consumed as the accumulator of a 16x16x16 step gave wrong rows
+        // (which is why tap 8 is a zero-padded K = 32 step too).  This direction tested clean; the wait is insurance
+        // and only border tiles pay it.
+        if constexpr (K32W && sizeof(T) == 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     }
+    if constexpr (K32W && sizeof(T) == 2) {
+        const int band = y * (Halo<T>::CPP * HW * Halo<T>::EPC);
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int off = Halo<T>::off(y + dy, m + dx, q);
-            const frag_t a = *reinterpret_cast<const frag_t*>(tile + off);
-            mma16(acc, rw.wc[dy * 3 + dx], a);      // c1^T = W'^T h1^T
+        for (int pr = 0; pr < 5; ++pr) {          // taps (2p, 2p+1) and (8, -): one K = 32 step each (see mma32)
+            const s16x8 a = *reinterpret_cast<const s16x8*>(tile + band + w.xo[pr]);
+            mma32(acc, rw.w2[pr], a);
             if constexpr (JVP) {
-                const frag_t ad = *reinterpret_cast<const frag_t*>(tiled + off);
-                mma16(accd, rw.wc[dy * 3 + dx], ad);
-                mma16(accd, rw.wcd[dy * 3 + dx], a);
+                const s16x8 ad = *reinterpret_cast<const s16x8*>(tiled + band + w.xo[pr]);
+                mma32(accd, rw.w2[pr], ad);
+                mma32(accd, rw.w2d[pr], a);
             }
         }
+    } else {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int off = Halo<T>::off(y + dy, m + dx, q);
+                const frag_t a = *reinterpret_cast<const frag_t*>(tile + off);
+                mma16(acc, rw.wc[dy * 3 + dx], a);      // c1^T = W'^T h1^T
+                if constexpr (JVP) {
+                    const frag_t ad = *reinterpret_cast<const frag_t*>(tiled + off);
+                    mma16(accd, rw.wc[dy * 3 + dx], ad);
+                    mma16(accd, rw.wcd[dy * 3 + dx], a);
+                }
+            }
+    }
     float v[4] = {acc[0], acc[1], acc[2], acc[3]}, mean;
     ln_fwd_a(v, o.n1, mean, o.rho1);
     make_frag(o.n1f, o.n1[0], o.n1[1], o.n1[2], o.n1[3]);
@@ -507,7 +577,7 @@ cnx_fwd_kernel(FwdArgs a) {
     const T* h0d = (const T*)a.h0d;
     Halo<T> hl;
     hl.init(s, wave, lane);
-    RowW<T, JVP> rw;
+    RowW<T, JVP, JVP> rw;
     constexpr int S_VMEM = MODE == 1 ? RPW * (JVP ? 2 : 1) : 0;   // stores between a DMA request and its wait
 
     int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
@@ -587,7 +657,7 @@ cnx_fwd_kernel(FwdArgs a) {
             const int gy = y0 + y;
             const bool ok = gy < s && gx < s;
             RowFwd<T, JVP> f;
-            chain_row<T, JVP, false>(tile, tiled, l.wc0, w, rw, border, gy, gx, s, y, q, m, lane, f);
+            chain_row<T, JVP, false, JVP>(tile, tiled, l.wc0, w, rw, border, gy, gx, s, y, q, m, lane, f);
             if constexpr (MODE == 0) {
                 if (ok) {
 #pragma unroll
