@@ -167,6 +167,8 @@ def summarize_timing(records, steps):
     for name, ints, nn, s, e in records:
         if name == "mfc_adamw":
             ints = ints[:2]          # drop the step counter from the key
+        elif name == "mfc_gemm_adamw":
+            ints = ints[:6]          # (flags, M, N, K, lda, ldb): drop the step counter
         key = (name, ints, nn)
         ms = s.elapsed_time(e)
         a = agg.setdefault(key, [0.0, 0])
