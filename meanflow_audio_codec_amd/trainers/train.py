@@ -89,6 +89,26 @@ def create_flow_model(config, noise_dimension: int, dtype=torch.float32):
     raise ValueError(f"Unknown architecture: {arch}")
 
 
+def load_flow_state(config, checkpoint_path, batch_size: int | None = None, *, dtype=torch.float32, device="cuda"):
+    """``load_flow_state`` of trainers/utils.py:439-470: build the model of ``config`` (a ``TrainFlowConfig`` or its
+    ``to_dict()``), wrap it in a TrainState and fill it from the checkpoint.  Unlike the reference -- which always
+    builds the MLP at ``noise_dimension`` -- the architecture and the tokenised dimension of the config are honoured,
+    as in ``train_flow``.  ``batch_size`` is accepted for signature compatibility (nothing here is traced).
+    Returns ``(model, state)``."""
+    from . import checkpoint as ck
+    if isinstance(config, dict):
+        from ..configs import TrainFlowConfig
+        config = TrainFlowConfig.from_dict(config)
+    tokenization = create_tokenization_strategy(config)
+    D = (compute_tokenized_dimension(tokenization, config.noise_dimension, config.dataset or "mnist")
+         if tokenization is not None else config.noise_dimension)
+    model = create_flow_model(config, D, dtype=dtype)
+    params = model.init(seed=0, device=device)
+    state = TrainState.create(apply_fn=model.apply, params=params,
+                              tx=adamw(config.base_lr, config.weight_decay), model=model)
+    return model, ck.load_checkpoint(Path(checkpoint_path), state)
+
+
 def synthetic_iterator(config, device="cuda", scale: float = 0.1):
     """Endless ``[batch_size, noise_dimension]`` float32 batches ~ scale * N(0,1), seeded by ``config.seed`` (the
     measurement input of SURVEY 8(d); the dataset front end is row N4 and not built)."""
