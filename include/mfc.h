@@ -69,6 +69,21 @@ int mfc_mdct_inv(const float* X, int64_t B, int64_t n_frames, int N, int hop,
                  float* y, int64_t ldy, void* stream);
 
 /* ------------------------------------------------------------------ */
+/* Data front end (datasets/audio.py)                                  */
+/* ------------------------------------------------------------------ */
+
+/* Rational-ratio polyphase resampler: the device-side step between the
+ * reference's 44.1 kHz-only loader (datasets/audio.py:236-262 keeps the file rate)
+ * and the 24 kHz clips of the audio configuration.
+ *   y[r,n] = sum_j x[r,j] * h[n*down - j*up + (nh-1)/2],  0 <= n < T_out = ceil(T_in*up/down)
+ * (scipy.signal.resample_poly, padtype="constant"; h = odd-length low-pass at rate
+ * up*fs_in, already multiplied by up).  x [rows, T_in] fp32 (row stride ldx),
+ * y [rows, T_out] fp32 (row stride ldy), h [nh] fp32 on the device, nh odd, <= 16384. */
+int64_t mfc_resample_out_len(int64_t T_in, int up, int down);
+int mfc_resample_poly(const float* x, int64_t rows, int64_t T_in, int64_t ldx, int up, int down,
+                      const float* h, int nh, float* y, int64_t ldy, void* stream);
+
+/* ------------------------------------------------------------------ */
 /* Dense layers (flax.linen.Dense call sites: models/mlp_flow.py:18-31,  */
 /* models/conv_flow.py:142-160,188-202, models/mlp_mixer.py)            */
 /* ------------------------------------------------------------------ */

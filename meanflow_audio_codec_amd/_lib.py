@@ -41,6 +41,8 @@ SIGNATURES = {
     "mfc_mdct_out_len": (c_int64, [c_int64, c_int, c_int]),
     "mfc_mdct_fwd": (c_int, [_P, c_int64, c_int64, c_int64, c_int, c_int, _P, _P]),
     "mfc_mdct_inv": (c_int, [_P, c_int64, c_int64, c_int, c_int, _P, c_int64, _P]),
+    "mfc_resample_out_len": (c_int64, [c_int64, c_int, c_int]),
+    "mfc_resample_poly": (c_int, [_P, c_int64, c_int64, c_int64, c_int, c_int, _P, c_int, _P, c_int64, _P]),
     "mfc_gemm": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64,
                          _P, c_int64, c_int64, c_float, _P, c_int64, c_float, c_int, _P, _P, _P]),
     "mfc_ln16_fwd": (c_int, [c_int, c_int64, _P, _P, _P, _P]),

@@ -1,6 +1,8 @@
 """Command line of the reference's ``train.py`` (repo root there): ``--config``, ``--workdir``, ``--resume`` and the
-flow-model overrides, on this backend.  The dataset front end is not part of this build, so batches
-are the synthetic ``0.1 * N(0,1)`` clips of the benchmark unless a caller passes its own iterator to ``train_flow``.
+flow-model overrides, on this backend.  Batches come from ``config.data_dir`` through the dataset front end
+(``datasets/``: MNIST IDX files, or ``.mp3`` / ``.wav`` audio, ``--target-sr`` resampling on the device) as in the
+reference (a config without ``data_dir`` is an error there and here); ``--synthetic`` trains on the benchmark's
+``0.1 * N(0,1)`` clips instead.
 
     python -m meanflow_audio_codec_amd.train_cli --config configs/<name>.json --workdir runs/x [--resume]
 """
@@ -30,6 +32,9 @@ def build_parser() -> argparse.ArgumentParser:
     b = p.add_argument_group("Backend")
     b.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32", help="storage dtype of the big kernels")
     b.add_argument("--steps", type=int, default=None, help="stop after this many steps (default: config.n_steps)")
+    b.add_argument("--synthetic", action="store_true", help="train on synthetic clips instead of config.data_dir")
+    b.add_argument("--target-sr", type=int, default=None,
+                   help="resample every audio file to this rate on the device (the reference keeps 44.1 kHz files)")
     return p
 
 
@@ -37,7 +42,10 @@ def config_from_args(args):
     from .configs import TrainFlowConfig, load_config_from_json, merge_configs
     if args.config:
         # (the reference assigns config.workdir, which its read-only property rejects; the override is merged here)
-        return merge_configs(load_config_from_json(args.config), {"workdir": str(args.workdir)})
+        override = {"workdir": str(args.workdir)}
+        if args.data_dir is not None:       # the shipped configs carry "data_dir": null
+            override["data_dir"] = args.data_dir
+        return merge_configs(load_config_from_json(args.config), override)
     missing = [a for a in _REQUIRED_WITHOUT_CONFIG if getattr(args, a) is None]
     if missing:
         raise SystemExit("Missing required arguments (or pass --config): " + ", ".join("--" + m.replace("_", "-") for m in missing))
@@ -52,7 +60,8 @@ def main(argv=None) -> int:
     import torch
     from .trainers.train import synthetic_iterator, train_flow
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    train_flow(config, synthetic_iterator(config), resume=args.resume, n_steps=args.steps, dtype=dtype)
+    data = synthetic_iterator(config) if args.synthetic else None
+    train_flow(config, data, resume=args.resume, n_steps=args.steps, dtype=dtype, target_sr=args.target_sr)
     return 0
 
 

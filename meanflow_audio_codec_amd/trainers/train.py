@@ -109,6 +109,33 @@ def load_flow_state(config, checkpoint_path, batch_size: int | None = None, *, d
     return model, ck.load_checkpoint(Path(checkpoint_path), state)
 
 
+def dataset_iterator(config, device="cuda", target_sr: int | None = None, rank: int = 0, world: int = 1):
+    """The data side of trainers/train.py:281-306: ``[B, noise_dimension]`` float32 batches from ``config.data_dir``.
+
+    * ``mnist``: ``load_mnist(split="train")`` images (labels dropped), :283-289.
+    * ``audio``: ``build_audio_pipeline(frame_sz=noise_dimension, seed, batch_size)``, frames kept in HBM; ``.mp3`` and
+      ``.wav`` files; ``target_sr`` converts each file on the device.  The reference flattens the
+      ``[B, frame_sz, n_channels]`` batch to ``[B, frame_sz * n_channels]`` (:298-303), which no longer has the
+      model's ``noise_dimension`` for the two-channel frames its own loader always produces; here the channels are
+      averaged to one so that the configured dimension holds.  (The two-channel token layout of ``MDCTLayer`` --
+      L/R concatenated on the coefficient axis -- is what ``MDCTTokenization.tokenize`` does with a ``[B, T, 2]`` batch.)
+    * data parallel: rank ``r`` of ``world`` seeds its pipeline with ``seed + r``, i.e. draws its own stream."""
+    from ..datasets import build_audio_pipeline, load_mnist
+    name = config.dataset or "mnist"
+    seed = int(config.seed) + int(rank)
+    if name == "mnist":
+        for img, _ in load_mnist(data_dir=str(config.data_dir), split="train", batch_size=config.batch_size, seed=42 + rank):
+            yield img
+    elif name == "audio":
+        it = build_audio_pipeline(data_dir=str(config.data_dir), seed=seed, frame_sz=config.noise_dimension,
+                                  batch_size=config.batch_size, device=device, target_sr=target_sr,
+                                  extensions=(".mp3", ".wav"))
+        for b in it:
+            yield b.mean(dim=2) if b.ndim == 3 else b
+    else:
+        raise ValueError(f"Unknown dataset: {name}")
+
+
 def synthetic_iterator(config, device="cuda", scale: float = 0.1):
     """Endless ``[batch_size, noise_dimension]`` float32 batches ~ scale * N(0,1), seeded by ``config.seed`` (the
     measurement input of SURVEY 8(d); the dataset front end is row N4 and not built)."""
@@ -146,12 +173,12 @@ def _save_samples(samples_dir: Path, step: int, smps: torch.Tensor, config, orig
 
 def train_flow(config, data_iterator=None, *, resume: bool = False, n_steps: int | None = None,
                dtype=torch.float32, device="cuda", log_path: str | Path | None = None, reducer=None,
-               rank: int = 0, world: int = 1, workdir: str | Path | None = None):
+               rank: int = 0, world: int = 1, workdir: str | Path | None = None, target_sr: int | None = None):
     """``train_flow`` of trainers/train.py:156-507 on this backend.
 
     ``data_iterator`` yields float32 ``[B, noise_dimension]`` host or device batches (the reference's iterator
-    contract, :283-306); without one ``config.data_dir`` must be set as in the reference (:168-173) -- and since the
-    dataset front end is not built, a set ``data_dir`` still raises ``NotImplementedError``.
+    contract, :283-306); without one the batches come from ``config.data_dir`` through ``dataset_iterator`` (the
+    reference's MNIST / audio pipelines; ``target_sr`` resamples the audio files on the device).
 
     With a work directory (``workdir`` argument or ``config.workdir``) rank 0 writes the reference's layout:
     ``config.json``, ``metadata.json``, ``config_diff.json`` (on resume), ``logs/train_log.jsonl``,
@@ -166,8 +193,7 @@ def train_flow(config, data_iterator=None, *, resume: bool = False, n_steps: int
         if config.data_dir is None:
             raise ValueError("config.data_dir must be provided. It cannot be None. "
                              "Please specify a valid data directory path in your configuration.")
-        raise NotImplementedError("the dataset front end (datasets/audio.py, datasets/mnist.py) is not part of this "
-                                  "build: pass data_iterator (e.g. synthetic_iterator(config))")
+        data_iterator = dataset_iterator(config, device=device, target_sr=target_sr, rank=rank, world=world)
     tokenization = create_tokenization_strategy(config)
     dataset = config.dataset or "mnist"
     if tokenization is not None:

@@ -84,8 +84,8 @@ def test_requires_data_source_and_even_condition_dimension(tmp_path):
         train_flow(cfg)
     with pytest.raises(ValueError, match="even"):      # already rejected by the config's own validation
         _config(tmp_path / "b", condition_dimension=15)
-    with pytest.raises(NotImplementedError):
-        train_flow(_config(tmp_path / "c", data_dir="/data"))
+    with pytest.raises(FileNotFoundError):             # the MNIST IDX files are looked up in data_dir
+        train_flow(_config(tmp_path / "c", data_dir=str(tmp_path)))
 
 
 def test_cli_runs_a_config_file(tmp_path):
@@ -95,6 +95,9 @@ def test_cli_runs_a_config_file(tmp_path):
                                     weight_decay=1e-4, seed=1, noise_dimension=32, condition_dimension=16,
                                     latent_dimension=8, num_blocks=1, dataset="mnist", architecture="mlp",
                                     use_improved_mean_flow=False)))
-    assert train_cli.main(["--config", str(cfgp), "--workdir", str(tmp_path / "w")]) == 0
+    with pytest.raises(ValueError, match="data_dir"):      # as the reference: no data_dir, no training
+        train_cli.main(["--config", str(cfgp), "--workdir", str(tmp_path / "w0")])
+    assert train_cli.main(["--config", str(cfgp), "--workdir", str(tmp_path / "w"), "--synthetic"]) == 0
     assert (tmp_path / "w" / "checkpoints" / "step_00002.msgpack").exists()
-    assert train_cli.main(["--config", str(cfgp), "--workdir", str(tmp_path / "w"), "--resume", "--steps", "2"]) == 0
+    assert train_cli.main(["--config", str(cfgp), "--workdir", str(tmp_path / "w"), "--resume", "--steps", "2",
+                           "--synthetic"]) == 0
