@@ -15,6 +15,12 @@ all-reduce, but each GPU streams only 1/world of the 28 B/parameter optimizer tr
 at 8 GPUs).  A rank's fp32 master and moments are then authoritative only on its own slice; ``gather_master`` restores
 the full tensors everywhere (before a checkpoint).  gloo has no reduce-scatter: there the same slices are produced
 with an all-reduce and ``all_gather`` on views, so the CPU / single-GPU rehearsals run the same index arithmetic.
+
+Deferred gather (``defer_gather``, default on): the links are busy with the reduce-scatters for most of the reverse
+pass, so the all-gathers are not interleaved with them but issued together once the reverse pass is done, first block
+first; each leaves an event in ``state.work.pending`` and the next step's forward waits per leaf, at its first read
+(``models/train_state.py::WorkDict``).  The all-gather phase then overlaps the next forward instead of sitting between
+two steps; AdamW writes its bf16 slice straight into the working copy and the all-gather runs in place on it.
 """
 from __future__ import annotations
 
@@ -36,6 +42,7 @@ class GradReducer:
         if shard_optimizer is None:
             shard_optimizer = os.environ.get("MFC_SHARD_OPTIMIZER", "1") != "0"
         self.shard_optimizer = bool(shard_optimizer) and self.world > 1
+        self.defer_gather = self.shard_optimizer and os.environ.get("MFC_DEFER_GATHER", "1") != "0"
         self._native = dist.get_backend(group) == "nccl"     # reduce_scatter_tensor / all_gather_into_tensor
         self._tmp = {}
         self.sharded: set = set()                            # leaves whose master / moments live in slices
@@ -61,7 +68,7 @@ class GradReducer:
         out.copy_(full[self.rank * out.numel():(self.rank + 1) * out.numel()])
 
     def _all_gather(self, full: torch.Tensor, mine: torch.Tensor) -> None:
-        """full (flat) <- concatenation over ranks of ``mine``."""
+        """full (flat) <- concatenation over ranks of ``mine``; ``mine`` may be this rank's slice of ``full`` (in place)."""
         if self._native:
             try:
                 dist.all_gather_into_tensor(full, mine, group=self.group)
@@ -70,18 +77,22 @@ class GradReducer:
                 print(f"[mfc] all_gather_into_tensor unavailable ({e}); using all_gather", flush=True)
                 self._native = False
         n = mine.numel()
+        if mine.data_ptr() == full[self.rank * n:(self.rank + 1) * n].data_ptr():
+            mine = mine.clone()
         dist.all_gather([full[r * n:(r + 1) * n] for r in range(self.world)], mine, group=self.group)
 
     def shardable(self, state, name: str, grad: torch.Tensor) -> bool:
-        w = state.work.get(name)
+        w = dict.get(state.work, name)          # raw access: never consume a pending-gather event on this stream
         return (self.shard_optimizer and w is not None and w.dtype == torch.bfloat16 and grad.dtype == torch.bfloat16
                 and grad.is_contiguous() and w.is_contiguous() and grad.numel() > self.small_numel
                 and grad.numel() % (self.world * 64) == 0)
 
-    def sharded_update(self, state, names, grads: dict) -> list:
+    def sharded_update(self, state, names, grads: dict, defer: list | None = None) -> list:
         """One optimizer step (``state.step`` already advanced by ``begin_update``) of every shardable leaf in ``names``:
-        reduce-scatter the gradient, AdamW on the own slice, all-gather the bf16 working copy.  Returns the names that
-        were NOT handled (small / fp32 leaves: all-reduce + full AdamW, the caller's job)."""
+        reduce-scatter the gradient, AdamW on the own slice (the bf16 result goes straight into this rank's slice of
+        the working copy), all-gather the working copy in place -- now, or, with ``defer`` (a list the names are
+        appended to), later in ``flush_gathers``.  Returns the names that were NOT handled (small / fp32 leaves:
+        all-reduce + full AdamW, the caller's job)."""
         from . import ops
         rest = []
         tx = state.tx
@@ -95,16 +106,43 @@ class GradReducer:
             lo = self.rank * sh
             gsh = self._buf(("g", sh), sh, torch.bfloat16, g.device)
             self._reduce_scatter(gsh, g.view(-1))
-            wsh = self._buf(("w", sh), sh, torch.bfloat16, g.device)
+            wflat = dict.__getitem__(state.work, k).view(-1)
             ops.adamw(state.params[k].view(-1)[lo:lo + sh], gsh, state.opt_state["mu"][k].view(-1)[lo:lo + sh],
                       state.opt_state["nu"][k].view(-1)[lo:lo + sh], lr=tx.learning_rate, wd=tx.weight_decay,
-                      step=state.step, b1=tx.b1, b2=tx.b2, eps=tx.eps, p_bf16=wsh)
-            self._all_gather(state.work[k].view(-1), wsh)
+                      step=state.step, b1=tx.b1, b2=tx.b2, eps=tx.eps, p_bf16=wflat[lo:lo + sh])
+            if defer is None:
+                self._all_gather(wflat, wflat[lo:lo + sh])
+            else:
+                defer.append(k)
             self.sharded.add(k)
         return rest
 
+    @staticmethod
+    def _use_order(name: str):
+        """Order in which a forward pass first reads the big kernels: block by block, and inside a block
+        input_proj1 -> input_proj2 -> output_proj1 -> output_proj2 (models/conv_flow.py); other names keep their order."""
+        parts = name.split("/")
+        blk = int(parts[0].split("_")[1]) if parts[0].startswith("blocks_") and parts[0].split("_")[1].isdigit() else 1 << 30
+        within = {"input_proj1": 0, "input_proj2": 1, "output_proj1": 2, "output_proj2": 3}.get(
+            parts[1] if len(parts) > 1 else "", 4)
+        return (blk, within)
+
+    def flush_gathers(self, state, names: list) -> None:
+        """All-gather (in place) the working copy of every deferred leaf on the CURRENT stream, in the order the next
+        forward reads them; each leaf gets an event in ``state.work.pending``."""
+        for k in sorted(names, key=self._use_order):
+            wflat = dict.__getitem__(state.work, k).view(-1)
+            sh = wflat.numel() // self.world
+            self._all_gather(wflat, wflat[self.rank * sh:(self.rank + 1) * sh])
+            if wflat.is_cuda and hasattr(state.work, "pending"):
+                ev = torch.cuda.Event()
+                ev.record()
+                state.work.pending[k] = ev
+        del names[:]
+
     def gather_master(self, state) -> None:
         """Make the fp32 master and both moments of every sharded leaf complete on every rank (checkpointing)."""
+        getattr(state.work, "wait_all", lambda: None)()
         for k in sorted(self.sharded):
             for t in (state.params[k], state.opt_state["mu"][k], state.opt_state["nu"][k]):
                 flat = t.view(-1)

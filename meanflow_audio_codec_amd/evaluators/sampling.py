@@ -104,6 +104,7 @@ class GraphedDecoder:
             return x0
 
         self._body = body
+        getattr(w, "wait_all", lambda: None)()   # no in-flight weight gathers may be awaited inside the capture
         self._draw()
         body()                                   # warm-up: allocations, function attributes
         torch.cuda.synchronize()

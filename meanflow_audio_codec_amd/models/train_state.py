@@ -30,6 +30,37 @@ def adamw(learning_rate: float, weight_decay: float = 1e-4, b1: float = 0.9, b2:
     return AdamW(learning_rate, weight_decay, b1, b2, eps)
 
 
+class WorkDict(dict):
+    """The working copies the kernels read, keyed by leaf name.  A leaf whose all-gather from the previous optimizer
+    step is still in flight on the side stream (``distributed.GradReducer.flush_gathers``) carries an event in
+    ``pending``; the first ``w[name]`` / ``w.get(name)`` makes the CURRENT stream wait for it, so the next forward pass
+    starts while later blocks are still being gathered.  ``wait_all`` does so for everything (graph capture,
+    ``refresh_work``, anything that walks ``values()``)."""
+
+    def __init__(self):
+        super().__init__()
+        self.pending: dict = {}
+
+    def _arrive(self, k):
+        ev = self.pending.pop(k, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def __getitem__(self, k):
+        if self.pending:
+            self._arrive(k)
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        if self.pending:
+            self._arrive(k)
+        return dict.get(self, k, default)
+
+    def wait_all(self):
+        for k in list(self.pending):
+            self._arrive(k)
+
+
 class TrainState:
     def __init__(self, apply_fn, params: dict, tx: AdamW, model=None, step: int = 0, opt_state=None):
         self.apply_fn = apply_fn
@@ -41,7 +72,7 @@ class TrainState:
             "mu": {k: torch.zeros_like(v) for k, v in params.items()},
             "nu": {k: torch.zeros_like(v) for k, v in params.items()},
         }
-        self.work = {}                  # what the kernels read
+        self.work = WorkDict()          # what the kernels read
         self._grads = None
         self.refresh_work()
 
@@ -55,6 +86,7 @@ class TrainState:
         return torch.float32
 
     def refresh_work(self):
+        self.work.wait_all()
         for k, p in self.params.items():
             dt = self._work_dtype(k)
             if dt == torch.float32:

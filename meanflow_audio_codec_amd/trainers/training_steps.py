@@ -55,9 +55,12 @@ def _train_step_with_strategy(state, key, x, loss_strategy: LossStrategy, *, red
         loss, grads = loss_strategy.compute_loss(state, key, x, row0=row0, global_batch=global_batch)
         if reducer is not None and reducer.shard_optimizer:
             state.begin_update()
-            rest = reducer.sharded_update(state, list(state.params), grads)
+            defer = [] if reducer.defer_gather else None
+            rest = reducer.sharded_update(state, list(state.params), grads, defer=defer)
             loss = reducer.reduce({k: grads[k] for k in rest}, loss)
             state.apply_subset(rest, grads)
+            if defer:
+                reducer.flush_gathers(state, defer)
             return state, loss, key.next()
         if reducer is not None:
             loss = reducer.reduce(grads, loss)
@@ -70,6 +73,8 @@ def _train_step_with_strategy(state, key, x, loss_strategy: LossStrategy, *, red
     state.begin_update()
     done = set()
     grads_ref = state.grad_buffers()
+    # deferred all-gathers: issued after the reverse pass, awaited leaf by leaf by the next forward (distributed.py)
+    defer = [] if (reducer is not None and reducer.shard_optimizer and reducer.defer_gather) else None
 
     def on_block(names):
         ev = torch.cuda.Event()
@@ -79,7 +84,8 @@ def _train_step_with_strategy(state, key, x, loss_strategy: LossStrategy, *, red
             rest = names
             if reducer is not None:
                 # big kernels: reduce-scatter -> AdamW on the own slice -> all-gather (distributed.py); the rest all-reduce
-                rest = reducer.sharded_update(state, names, grads_ref) if reducer.shard_optimizer else names
+                rest = (reducer.sharded_update(state, names, grads_ref, defer=defer) if reducer.shard_optimizer
+                        else names)
                 reducer.reduce_tensors([grads_ref[n] for n in rest])
             state.apply_subset(rest, grads_ref)
         done.update(names)
@@ -89,8 +95,15 @@ def _train_step_with_strategy(state, key, x, loss_strategy: LossStrategy, *, red
     if rest:
         on_block(rest)
     if reducer is not None:
-        loss = reducer.reduce_scalar(loss)
-    main.wait_stream(side)                 # the next forward reads the updated weights
+        loss = reducer.reduce_scalar(loss)     # queued ahead of the gathers below (collectives run in issue order)
+    if defer:
+        updated = torch.cuda.Event()
+        updated.record(side)                   # every gradient consumed, every master / moment / small leaf updated
+        with torch.cuda.stream(side):
+            reducer.flush_gathers(state, defer)
+        main.wait_event(updated)               # working copies of the big kernels: per-leaf events in state.work.pending
+    else:
+        main.wait_stream(side)                 # the next forward reads the updated weights
     return state, loss, key.next()
 
 

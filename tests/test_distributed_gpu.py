@@ -1,5 +1,6 @@
 """GPU, two ranks on one device over gloo: the data-parallel train step with the sharded optimizer (reduce-scatter ->
-AdamW on the own slice -> all-gather) against the plain all-reduce + full AdamW schedule."""
+AdamW on the own slice -> all-gather, the gathers deferred into the next forward or not) against the plain all-reduce +
+full AdamW schedule."""
 import os
 import socket
 
@@ -36,6 +37,8 @@ def _run(rank, world, shard, overlap, steps=2):
     for _ in range(steps):
         state, loss, key = train_step(state, key, x, ImprovedMeanFlowLoss(), reducer=red, row0=rank * B,
                                       global_batch=world * B, overlap=overlap)
+    # deferred gathers: every sharded leaf of the last step has an event waiting for its first reader
+    assert len(state.work.pending) == (len(red.sharded) if red.defer_gather else 0)
     torch.cuda.synchronize()
     return state, red, loss.item()
 
@@ -46,13 +49,20 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ref, _, loss_ref = _run(rank, world, shard=False, overlap=False)
-        for overlap in (False, True):
-            st, red, loss = _run(rank, world, shard=True, overlap=overlap)
+        for overlap, defer in ((False, "1"), (True, "1"), (True, "0")):
+            os.environ["MFC_DEFER_GATHER"] = defer
+            st, red, loss = _run(rank, world, shard=True, overlap=overlap, steps=3 if defer == "1" else 2)
+            assert red.defer_gather == (defer == "1")
+            if defer == "1":       # one more step than the reference run: only the bookkeeping is compared below
+                ref3, _, loss_ref3 = _run(rank, world, shard=False, overlap=False, steps=3)
+                ref_now, loss_now = ref3, loss_ref3
+            else:
+                ref_now, loss_now = ref, loss_ref
             big = sorted(red.sharded)
             assert sum(k.startswith("blocks_") for k in big) == 8 and all(k.endswith("/kernel") for k in big), big
-            assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+            assert abs(loss - loss_now) < 1e-4 * max(1.0, abs(loss_now))
             for k in st.work:       # what the kernels read agrees with the all-reduce schedule (atomic-order noise only)
-                d = (st.work[k].float() - ref.work[k].float()).abs()
+                d = (st.work[k].float() - ref_now.work[k].float()).abs()
                 assert d.max().item() < 5e-3 and (d > 1e-4).float().mean().item() < 0.05, (k, d.max().item())
             # masters / moments are authoritative on the own slice only ...
             k0 = big[0]
