@@ -101,14 +101,21 @@ def header_symbols() -> list[str]:
 _timing = None  # list of (name, int-args, non-null-pointer mask, start_event, end_event) while enabled
 
 
-def enable_timing():
-    global _timing
+_timing_only = None  # optional predicate (name, ints, nn) -> bool: which calls get events
+
+
+def enable_timing(only=None):
+    """Bracket launching C-ABI calls with HIP events; ``only(name, int_args, non_null_pointer_mask)`` restricts that to
+    the calls it accepts (every event pair costs a few microseconds of GPU time, so timing 500 launches per step slows
+    the step it measures by a few percent; timing one kernel does not)."""
+    global _timing, _timing_only
     _timing = []
+    _timing_only = only
 
 
 def disable_timing():
-    global _timing
-    rec, _timing = _timing, None
+    global _timing, _timing_only
+    rec, _timing, _timing_only = _timing, None, None
     return rec or []
 
 
@@ -128,6 +135,8 @@ class _Proxy:
         def timed(*args):
             ints = tuple(int(a) for a, ty in zip(args, argtypes) if ty in (c_int, c_int64) and a is not None)
             nn = tuple(bool(a) for a, ty in zip(args, argtypes) if ty is c_void_p)
+            if _timing_only is not None and not _timing_only(name, ints, nn):
+                return fn(*args)
             s = torch.cuda.Event(enable_timing=True)
             e = torch.cuda.Event(enable_timing=True)
             s.record()
