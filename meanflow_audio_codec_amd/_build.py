@@ -51,7 +51,11 @@ def build(force: bool = False, verbose: bool = True, jobs: int = 4) -> pathlib.P
         src, obj = job
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", str(src), "-o", str(obj),
                "-Wall", "-Wno-unused-function", "-munsafe-fp-atomics", "-Wno-inline-asm",
-               "-mllvm", "-amdgpu-mfma-vgpr-form=1"]   # MFMA results straight into VGPRs (no v_accvgpr_read traffic)
+               "-mllvm", "-amdgpu-mfma-vgpr-form=1",   # MFMA results straight into VGPRs (no v_accvgpr_read traffic)
+               # no SLP vectorisation: it turns adjacent scalar f32 ops into v_pk_{mul,add,fma}_f32, which on gfx950
+               # issue slower than the two scalar instructions they replace (MI355X_MICROARCH.md, packed f32 VALU) and
+               # cost registers; the VALU-bound ConvNeXt kernels run 2-4 % faster without (measured, -3.9 ms / step)
+               "-fno-slp-vectorize"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

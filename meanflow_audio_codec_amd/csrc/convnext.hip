@@ -63,6 +63,9 @@ __device__ inline void land(const s16x4& v) { asm volatile("" ::"v"(v)); }
 // sum over the 4 lanes sharing (lane & 15): lanes 16 and 32 apart.  gfx950's
 // v_permlane16_swap / v_permlane32_swap exchange 16-lane rows / 32-lane halves
 // in one VALU instruction (no LDS round trip as ds_bpermute would need).
+// (Measured alternative: the same sum as one v_mfma_f32_16x16x4_f32 with A = ones, which contracts over lane >> 4 on
+// the mostly idle matrix pipe -- 3-7 % SLOWER on every kernel here: the dependent read of the MFMA result stalls the
+// wave longer than the eight VALU instructions of the swap ladder take to issue.)
 __device__ inline float red_q(float v) {
     // inline asm: with the builtin and identical operands hipcc (ROCm 7.2) folds the two results
     // into one register.  "s_nop 1" = the 2 wait states a VALU-written operand needs before
@@ -73,6 +76,19 @@ __device__ inline float red_q(float v) {
     a = v; b = v;
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a: lo,lo  b: hi,hi
     return a + b;
+}
+// Two independent sums at once: the ladder carries x in the even rows and y in the odd rows, so three swaps (and two
+// adds) serve both -- same association ((q0+q1)+(q2+q3)) as red_q, bit-identical results.
+__device__ inline void red_q2(float& x, float& y) {
+    float a = x, b = y;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a: x0 y0 x2 y2   b: x1 y1 x3 y3
+    float t = a + b;                                                                 // x01 y01 x23 y23 (by row)
+    a = t; b = t;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a: x01 y01 x01 y01   b: x23 y23 x23 y23
+    t = a + b;                                                                       // X Y X Y
+    a = t; b = t;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a: X X X X   b: Y Y Y Y
+    x = a; y = b;
 }
 __device__ inline float red_m(float v) {  // sum over the 16 lanes sharing (lane >> 4)
     v += __shfl_xor(v, 1);
@@ -125,7 +141,7 @@ __device__ inline typename Frag<T>::type load_bfrag(const T* W, int sk, int sn, 
 __device__ inline void ln_fwd_a(const float v[4], float n[4], float& mean, float& rho) {
     float s = v[0] + v[1] + v[2] + v[3];
     float ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-    s = red_q(s); ss = red_q(ss);
+    red_q2(s, ss);
     mean = s * (1.0f / 16.0f);
     const float var = fmaxf(0.0f, ss * (1.0f / 16.0f) - mean * mean);
     rho = rsqrtf(var + LN_EPS);
@@ -144,8 +160,11 @@ __device__ inline void ln_jvp_a(const float vd[4], const float n[4], float rho, 
 }
 // backward of LayerNorm: dx = rho (dn - mean(dn) - n mean(dn n))
 __device__ inline void ln_bwd_a(const float dn[4], const float n[4], float rho, float dx[4]) {
-    const float m1 = red_q(dn[0] + dn[1] + dn[2] + dn[3]) * (1.0f / 16.0f);
-    const float m2 = red_q(dn[0] * n[0] + dn[1] * n[1] + dn[2] * n[2] + dn[3] * n[3]) * (1.0f / 16.0f);
+    float m1 = dn[0] + dn[1] + dn[2] + dn[3];
+    float m2 = dn[0] * n[0] + dn[1] * n[1] + dn[2] * n[2] + dn[3] * n[3];
+    red_q2(m1, m2);
+    m1 *= 1.0f / 16.0f;
+    m2 *= 1.0f / 16.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) dx[i] = rho * (dn[i] - m1 - n[i] * m2);
 }
