@@ -131,15 +131,15 @@ class _TwoTimeLoss(LossStrategy):
                 zdot = ops.cast(target[:n_tan].contiguous(), model.dtype)  # MeanFlow: tangent (e - x)
         u, dudt, ctx = model.forward(w, z, cond_u, xdot=zdot, cond_dot=cdot, latents=latents, save=True,
                                      ctx=ctx_holder)
-        loss, du, _ = ops.flow_loss(u, target, dudt=dudt, n_tan=n_tan, t=t, r=r, kind=self.kind, mode=mode, p=p,
-                                    c=c, Bglobal=Bg)
+        loss, du, pe = ops.flow_loss(u, target, dudt=dudt, n_tan=n_tan, t=t, r=r, kind=self.kind, mode=mode, p=p,
+                                     c=c, Bglobal=Bg)
         grads = state.grad_buffers()
         _, dcond, dlat = model.backward(w, ctx, du, grads, on_block=on_block, fused=fused)
         model.backward_conditioning(w, ctx, dcond, latents, grads, dlat=dlat)
         if aux is not None:
             inv = None if perm is None else torch.argsort(perm)
             un = (lambda a: a) if inv is None else (lambda a: a[inv])
-            aux.update(u=un(u), t=un(t), r=un(r), n_tan=n_tan,
+            aux.update(u=un(u), t=un(t), r=un(r), n_tan=n_tan, per_example=un(pe),
                        dudt=dudt, perm=perm, v=(zdot if use_v_pass else None))
         return loss, grads
 
