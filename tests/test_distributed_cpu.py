@@ -57,6 +57,24 @@ def _worker(rank, world, port, q):
         red._all_gather(gathered, mine)
         assert torch.equal(gathered, torch.arange(8 * world, dtype=torch.float32) * sum(range(1, world + 1)))
         assert red.shard_optimizer and red.rank == rank and not red._native
+        # in-place all-gather (the deferred gathers pass this rank's slice of the destination itself)
+        inplace = torch.zeros(8 * world)
+        inplace[rank * 8:(rank + 1) * 8] = mine
+        red._all_gather(inplace, inplace[rank * 8:(rank + 1) * 8])
+        assert torch.equal(inplace, gathered)
+        # flush_gathers on host tensors: gathers every deferred leaf in forward-use order, no events without a GPU
+        class _State:
+            work = {"blocks_1/output_proj1/kernel": torch.full((4 * world,), -1.0),
+                    "blocks_0/input_proj2/kernel": torch.full((4 * world,), -1.0)}
+        for w in _State.work.values():
+            w[rank * 4:(rank + 1) * 4] = float(rank + 1)
+        names = list(_State.work)
+        assert sorted(names, key=red._use_order) == ["blocks_0/input_proj2/kernel", "blocks_1/output_proj1/kernel"]
+        red.flush_gathers(_State, names)
+        assert names == []
+        for w in _State.work.values():
+            assert torch.equal(w, torch.arange(1, world + 1, dtype=torch.float32).repeat_interleave(4))
+        assert red.defer_gather
         # second call reuses the flat bucket
         total2 = red.reduce({k: v.clone() for k, v in ref.items()}, loss)
         assert abs(total2.item() - total.item()) < 1e-6
@@ -87,3 +105,18 @@ def test_reducer_requires_process_group():
         pytest.skip("process group already initialised")
     with pytest.raises(RuntimeError):
         GradReducer()
+
+
+def test_use_order_and_workdict_without_gpu():
+    from meanflow_audio_codec_amd.distributed import GradReducer
+    from meanflow_audio_codec_amd.models.train_state import WorkDict
+    names = ["blocks_10/input_proj1/kernel", "blocks_2/output_proj2/kernel", "blocks_2/input_proj1/kernel",
+             "encoder/dense1/kernel", "blocks_2/output_proj1/kernel", "blocks_2/input_proj2/kernel"]
+    assert sorted(names, key=GradReducer._use_order) == [
+        "blocks_2/input_proj1/kernel", "blocks_2/input_proj2/kernel", "blocks_2/output_proj1/kernel",
+        "blocks_2/output_proj2/kernel", "blocks_10/input_proj1/kernel", "encoder/dense1/kernel"]
+    w = WorkDict()
+    w["a"] = torch.ones(2)
+    assert w.pending == {} and torch.equal(w["a"], torch.ones(2)) and w.get("b") is None and w.get("a") is w["a"]
+    w.wait_all()                       # nothing pending: no device call
+    assert list(w) == ["a"] and len(w) == 1
