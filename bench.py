@@ -366,6 +366,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def unweighted_mse():
+        if rank != 0:
+            return None
+        try:
+            aux = {}
+            strat.compute_loss(state, key, tok.tokenize(clips).reshape(B, -1), row0=rank * B, global_batch=world * B,
+                               aux=aux)
+            return round(float(aux["per_example"].mean().item()) / D, 4)
+        except Exception as ex:  # informational only
+            return repr(ex)[:200]
+
+    mse_init = unweighted_mse()
     losses = []
     profile_rows, only = None, None
     for i in range(args.warmup):
@@ -401,16 +413,9 @@ def main():
         elapsed = tt.item()
     loss_vals = [float(l) for l in losses]
     # The weighted iMF loss is mean(pe / (pe + 1e-3)) with pe = the per-example squared error summed over D: it reads
-    # 1.0 whenever pe >> 1e-3.  One extra untimed evaluation reports the unweighted mean squared error beside it.
-    mse = None
-    if rank == 0:
-        try:
-            aux = {}
-            strat.compute_loss(state, key, tok.tokenize(clips).reshape(B, -1), row0=rank * B, global_batch=world * B,
-                               aux=aux)
-            mse = float(aux["per_example"].mean().item()) / D
-        except Exception as ex:  # informational only
-            mse = repr(ex)[:200]
+    # 1.0 whenever pe >> 1e-3.  Untimed evaluations before the first and after the last update report the unweighted
+    # mean squared error beside it.
+    mse_after = unweighted_mse()
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
@@ -423,7 +428,7 @@ def main():
                                f"(N={wl['window']}, hop={wl['hop']} -> D={D}), cond={wl['cond']}, latent={wl['latent']}, "
                                f"blocks={wl['blocks']}, {n_params / 1e9:.2f} B params, AdamW fp32 master",
                    "per_gpu_batch": B, "global_batch": world * B, "parallelism": f"dp{world}"},
-        "loss": loss_vals, "unweighted_mse_after_timed_steps": mse, "overlap_exchange_and_adamw": bool(use_overlap), "fused_weight_gradient_adamw": bool(use_fuse),
+        "loss": loss_vals, "unweighted_mse": {"at_init": mse_init, "after_timed_steps": mse_after}, "overlap_exchange_and_adamw": bool(use_overlap), "fused_weight_gradient_adamw": bool(use_fuse),
         "sharded_optimizer": bool(reducer is not None and getattr(reducer, "shard_optimizer", False)),
     }
 
