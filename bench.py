@@ -440,7 +440,9 @@ def main():
             rows = profile_rows          # all kernels, from the fully instrumented last warm-up step
             out["per_kernel_table_from"] = "last warm-up step (every launch between HIP events); roofline: timed steps"
         # the committed PMC table was collected on the literal bf16 workload at the default batch: null elsewhere
-        if out["roofline"] and not (args.workload == "literal" and args.dtype == "bf16" and B == WORKLOADS["literal"]["batch"]):
+        # (single GPU, fused weight-gradient + AdamW schedule -- the launch mix behind the per-symbol averages)
+        if out["roofline"] and not (args.workload == "literal" and args.dtype == "bf16" and world == 1 and use_fuse
+                                    and B == WORKLOADS["literal"]["batch"]):
             out["roofline"]["traffic"] = None
         out["sum_kernel_ms_per_step"] = round(sum(r["per_step_ms"] for r in rows), 2)
         out["launches_per_step"] = int(sum(r["launches"] for r in rows) / max(1, 1 if profile_rows is not None else args.steps))
