@@ -232,17 +232,20 @@ int mfc_time_embed(int64_t R, int dim, const float* t, const float* h, const flo
 /* sample_tr / logit_normal (meanflow_audio_codec/utils.py:32-45,
  * trainers/time_sampling.py:39-135) from a Philox stream keyed (seed, step,
  * GLOBAL row): t,r = sigmoid(N(mean,std)), t=max, r=min, global rows
- * < int(Bglobal*data_proportion) get r = t.  pair=0: only t (logit-normal). */
-int mfc_sample_tr(uint64_t seed, uint64_t step, int64_t row0, int64_t B, int64_t Bglobal, float mean,
-                  float std, float data_proportion, int pair, float* t, float* r, void* stream);
+ * < data_size get r = t.  data_size = int(Bglobal*data_proportion) is computed by the CALLER, once, in double
+ * precision as utils.py:41 does (the same integer then drives the host's row bookkeeping).  Local row i is global
+ * row row0 + i*row_stride (data-parallel shards: contiguous = stride 1, interleaved = stride world_size).
+ * pair=0: only t (logit-normal). */
+int mfc_sample_tr(uint64_t seed, uint64_t step, int64_t row0, int64_t row_stride, int64_t B, int64_t data_size,
+                  float mean, float std, int pair, float* t, float* r, void* stream);
 
 /* LinearNoiseSchedule (trainers/noise_schedules.py:52-88; noise_min=0, noise_max=1 gives the
  * UniformNoiseSchedule :91-115):  z = (1-t) x + (nmin + nmax t) e  [dtype],
- * target = nmax e - x [fp32].  e is drawn N(0,1) from Philox (seed, step, row0+b)
+ * target = nmax e - x [fp32].  e is drawn N(0,1) from Philox (seed, step, global row row0 + b*row_stride)
  * when e_in == NULL (and written to e_out if given). */
 int mfc_flow_prepare(int dtype, int64_t B, int64_t D, const float* x, const float* e_in,
                      const float* t, float noise_min, float noise_max, uint64_t seed, uint64_t step,
-                     int64_t row0, void* z, float* target, float* e_out, void* stream);
+                     int64_t row0, int64_t row_stride, void* z, float* target, float* e_out, void* stream);
 
 /* N(0,1) fp32 [B,D] keyed (seed, stream_id, row0+b): sampler start noise
  * (evaluators/sampling.py:50). */

@@ -67,10 +67,10 @@ SIGNATURES = {
     "mfc_copy2d": (c_int, [c_int, c_int64, c_int64, _P, c_int64, _P, c_int64, c_float, c_int, _P]),
     "mfc_transpose": (c_int, [c_int, c_int64, c_int, c_int, _P, _P, c_float, _P, _P]),
     "mfc_time_embed": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "mfc_sample_tr": (c_int, [c_uint64, c_uint64, c_int64, c_int64, c_int64, c_float, c_float, c_float, c_int,
+    "mfc_sample_tr": (c_int, [c_uint64, c_uint64, c_int64, c_int64, c_int64, c_int64, c_float, c_float, c_int,
                               _P, _P, _P]),
     "mfc_flow_prepare": (c_int, [c_int, c_int64, c_int64, _P, _P, _P, c_float, c_float, c_uint64, c_uint64,
-                                 c_int64, _P, _P, _P, _P]),
+                                 c_int64, c_int64, _P, _P, _P, _P]),
     "mfc_randn": (c_int, [c_uint64, c_uint64, c_int64, c_int64, c_int64, _P, _P]),
     "mfc_gelu_fwd": (c_int, [c_int, c_int64, c_int64, c_int64, _P, _P, _P]),
     "mfc_gelu_bwd": (c_int, [c_int, c_int64, _P, _P, _P, _P]),

@@ -78,20 +78,22 @@ __global__ void time_embed_kernel(int64_t R, int dim, const float* t, const floa
 }
 
 // ---- (t, r) sampling: meanflow_audio_codec/utils.py:32-45 --------------------
-// t,r = sigmoid(N(mean,std)); t=max, r=min; GLOBAL rows < int(Bglobal*prop): r = t.
-__global__ void sample_tr_kernel(uint64_t seed, uint64_t step, int64_t row0, int64_t B, int64_t Bglobal,
-                                 float mean, float stdv, float prop, int pair, float* t, float* r) {
+// t,r = sigmoid(N(mean,std)); t=max, r=min; GLOBAL rows < data_size: r = t.  data_size = int(Bglobal * data_proportion)
+// is computed ONCE on the host (as utils.sample_tr does) so kernel and host orchestration can never disagree.
+// Local row i is global row row0 + i * row_stride (data-parallel shards: contiguous stride 1, interleaved stride = world).
+__global__ void sample_tr_kernel(uint64_t seed, uint64_t step, int64_t row0, int64_t row_stride, int64_t B,
+                                 int64_t data_size, float mean, float stdv, int pair, float* t, float* r) {
     const int64_t i = blockIdx.x * (int64_t)ET + threadIdx.x;
     if (i >= B) return;
+    const int64_t grow = row0 + i * row_stride;
     float n[4];
-    normal4(seed, 0x7472u, (uint64_t)(row0 + i), (uint32_t)step, n);
+    normal4(seed, 0x7472u, (uint64_t)grow, (uint32_t)step, n);
     float a = 1.0f / (1.0f + expf(-(n[0] * stdv + mean)));
     if (!pair) { t[i] = a; return; }
     float b = 1.0f / (1.0f + expf(-(n[1] * stdv + mean)));
     const float tt = fmaxf(a, b), rr = fminf(a, b);
-    const int64_t data_size = (int64_t)((double)Bglobal * (double)prop);
     t[i] = tt;
-    r[i] = (row0 + i) < data_size ? tt : rr;
+    r[i] = grow < data_size ? tt : rr;
 }
 
 // ---- noise + interpolation + target -----------------------------------------
@@ -100,7 +102,7 @@ __global__ void sample_tr_kernel(uint64_t seed, uint64_t step, int64_t row0, int
 template <typename T>
 __global__ void flow_prepare_kernel(int64_t B, int64_t D, const float* x, const float* e_in, const float* t,
                                     float nmin, float nmax, uint64_t seed, uint64_t step, int64_t row0,
-                                    T* z, float* target, float* e_out) {
+                                    int64_t row_stride, T* z, float* target, float* e_out) {
     const int64_t quads = (D + 3) / 4;
     const int64_t total = B * quads;
     for (int64_t o = blockIdx.x * (int64_t)ET + threadIdx.x; o < total; o += (int64_t)gridDim.x * ET) {
@@ -111,7 +113,7 @@ __global__ void flow_prepare_kernel(int64_t B, int64_t D, const float* x, const 
 #pragma unroll
             for (int i = 0; i < 4; ++i) e4[i] = (4 * qd + i < D) ? e_in[b * D + 4 * qd + i] : 0.f;
         } else {
-            normal4(seed ^ (step * 0x9E3779B97F4A7C15ull), 0x6e6fu, (uint64_t)(row0 + b), (uint32_t)qd, e4);
+            normal4(seed ^ (step * 0x9E3779B97F4A7C15ull), 0x6e6fu, (uint64_t)(row0 + b * row_stride), (uint32_t)qd, e4);
         }
         const float tt = t[b];
         const float a = 1.0f - tt, c = nmin + nmax * tt;
@@ -378,28 +380,29 @@ extern "C" int mfc_time_embed(int64_t R, int dim, const float* t, const float* h
     return mfc_launch_status();
 }
 
-extern "C" int mfc_sample_tr(uint64_t seed, uint64_t step, int64_t row0, int64_t B, int64_t Bglobal, float mean,
-                             float std, float data_proportion, int pair, float* t, float* r, void* stream) {
+extern "C" int mfc_sample_tr(uint64_t seed, uint64_t step, int64_t row0, int64_t row_stride, int64_t B,
+                             int64_t data_size, float mean, float std, int pair, float* t, float* r, void* stream) {
     if (!t || (pair && !r)) return MFC_EFAULT;
-    if (B <= 0 || Bglobal < B || row0 < 0) return MFC_EINVAL;
-    hipLaunchKernelGGL(sample_tr_kernel, dim3(grid_for(B)), dim3(ET), 0, (hipStream_t)stream, seed, step, row0, B,
-                       Bglobal, mean, std, data_proportion, pair, t, r);
+    if (B <= 0 || row0 < 0 || row_stride < 1 || data_size < 0) return MFC_EINVAL;
+    hipLaunchKernelGGL(sample_tr_kernel, dim3(grid_for(B)), dim3(ET), 0, (hipStream_t)stream, seed, step, row0,
+                       row_stride, B, data_size, mean, std, pair, t, r);
     return mfc_launch_status();
 }
 
 extern "C" int mfc_flow_prepare(int dtype, int64_t B, int64_t D, const float* x, const float* e_in,
                                 const float* t, float noise_min, float noise_max, uint64_t seed, uint64_t step,
-                                int64_t row0, void* z, float* target, float* e_out, void* stream) {
+                                int64_t row0, int64_t row_stride, void* z, float* target, float* e_out,
+                                void* stream) {
     if (!x || !t || !z || !target) return MFC_EFAULT;
-    if (B <= 0 || D <= 0 || !DT_OK(dtype)) return MFC_EINVAL;
+    if (B <= 0 || D <= 0 || !DT_OK(dtype) || row0 < 0 || row_stride < 1) return MFC_EINVAL;
     const unsigned grid = grid_for(B * ((D + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MFC_F32)
         hipLaunchKernelGGL(flow_prepare_kernel<float>, dim3(grid), dim3(ET), 0, st, B, D, x, e_in, t, noise_min,
-                           noise_max, seed, step, row0, (float*)z, target, e_out);
+                           noise_max, seed, step, row0, row_stride, (float*)z, target, e_out);
     else
         hipLaunchKernelGGL(flow_prepare_kernel<u16>, dim3(grid), dim3(ET), 0, st, B, D, x, e_in, t, noise_min,
-                           noise_max, seed, step, row0, (u16*)z, target, e_out);
+                           noise_max, seed, step, row0, row_stride, (u16*)z, target, e_out);
     return mfc_launch_status();
 }
 

@@ -1,8 +1,11 @@
 """Data-parallel gradient exchange: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL
 over xGMI on ROCm; "gloo" on CPU for tests).
 
-The reference has no distributed path: this is new.  The batch is sharded across ranks
-(rank k owns global rows [k*B, (k+1)*B)); every loss already divides by the GLOBAL batch, so the
+The reference has no distributed path: this is new.  The batch is sharded across ranks,
+INTERLEAVED: rank k of G owns global rows k, k+G, k+2G, ... (``shard_rows``), so that the deterministic
+"first int(B*p) global rows have r = t" rule (utils.py:41-44) gives every rank the same share (+-1) of r == t
+rows (3 forward-equivalents of work) and of tangent rows (5) -- contiguous ownership would hand the first half
+of the ranks only cheap rows and make every step wait for the other half.  Every loss already divides by the GLOBAL batch, so the
 exchange is a plain SUM all-reduce of the gradient buffers between ``compute_loss`` and
 ``apply_gradients`` (trainers/training_steps.py:32-33 is where it slots in).  Big kernels are reduced
 in place tensor-by-tensor (each is its own multi-GB bucket, launched asynchronously so RCCL pipelines
@@ -21,6 +24,18 @@ pass, so the all-gathers are not interleaved with them but issued together once 
 first; each leaves an event in ``state.work.pending`` and the next step's forward waits per leaf, at its first read
 (``models/train_state.py::WorkDict``).  The all-gather phase then overlaps the next forward instead of sitting between
 two steps; AdamW writes its bf16 slice straight into the working copy and the all-gather runs in place on it.
+
+Precision of the exchange: the big kernels' gradients are stored, and summed across ranks, in bf16 (RCCL adds in
+fp32 inside one reduction step but every hop of the ring re-rounds the running sum to bf16: relative error
+<= ~log2(G) * 2^-9 of the summed gradient, the same order as the bf16 rounding of each rank's own contribution; the
+AdamW update normalises gradient magnitudes, so this noise moves an update by a fraction of lr).  Small leaves and the
+ConvNeXt interior's gradients are exchanged in fp32.
+
+Which collective is used (native ``reduce_scatter_tensor`` / ``all_gather_into_tensor`` or their all-reduce /
+all-gather emulation) is decided ONCE in ``__init__`` -- by backend, confirmed by a tiny probe collective whose verdict
+is min-reduced over the ranks -- so every rank always issues the same sequence of collectives.  Errors after that
+propagate (a rank that fails exits non-zero and the launcher tears the job down) instead of silently switching one
+rank to a different collective, which would hang its peers.
 """
 from __future__ import annotations
 
@@ -28,6 +43,17 @@ import os
 
 import torch
 import torch.distributed as dist
+
+
+def shard_rows(rank: int, world: int, per_rank_batch: int) -> dict:
+    """Row ownership of one rank under the interleaved layout: keyword arguments for ``train_step`` /
+    ``compute_loss`` (``row0``, ``row_stride``, ``global_batch``).  Local row i is global row rank + i * world."""
+    return dict(row0=int(rank), row_stride=int(world), global_batch=int(world) * int(per_rank_batch))
+
+
+def shard_of(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """This rank's rows of a global batch ``x`` [G*B, ...] under the interleaved layout."""
+    return x[rank::world].contiguous()
 
 
 class GradReducer:
@@ -43,9 +69,38 @@ class GradReducer:
             shard_optimizer = os.environ.get("MFC_SHARD_OPTIMIZER", "1") != "0"
         self.shard_optimizer = bool(shard_optimizer) and self.world > 1
         self.defer_gather = self.shard_optimizer and os.environ.get("MFC_DEFER_GATHER", "1") != "0"
-        self._native = dist.get_backend(group) == "nccl"     # reduce_scatter_tensor / all_gather_into_tensor
         self._tmp = {}
         self.sharded: set = set()                            # leaves whose master / moments live in slices
+        self._native = self._decide_native()                 # reduce_scatter_tensor / all_gather_into_tensor
+
+    def _decide_native(self) -> bool:
+        """Taken once, identically on every rank: native tensor collectives on RCCL, the emulation elsewhere (gloo has
+        no reduce-scatter).  ``MFC_DIST_NATIVE=0/1`` overrides the backend rule.  On a CUDA device the choice is
+        confirmed by running both collectives once on 64 floats; every rank contributes its verdict to a MIN
+        all-reduce, so one rank's failure moves ALL ranks to the emulation -- before any training traffic."""
+        env = os.environ.get("MFC_DIST_NATIVE")
+        native = (dist.get_backend(self.group) == "nccl") if env is None else (env == "1")
+        if not native or self.world == 1:
+            return False
+        ok = 1
+        dev = torch.device("cuda", torch.cuda.current_device())
+        try:
+            full = torch.ones(64 * self.world, dtype=torch.float32, device=dev)
+            out = torch.empty(64, dtype=torch.float32, device=dev)
+            dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(full, out, group=self.group)
+            torch.cuda.synchronize(dev)
+            if not bool((full == float(self.world)).all().item()):
+                ok = 0
+        except (RuntimeError, AttributeError, NotImplementedError, ValueError, TypeError) as e:
+            print(f"[mfc] rank {self.rank}: native reduce-scatter / all-gather probe failed ({e})", flush=True)
+            ok = 0
+        verdict = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=self.group)     # plain all-reduce: exists on every backend
+        native = bool(verdict.item())
+        if not native and self.rank == 0:
+            print("[mfc] sharded optimizer uses all_reduce / all_gather (native tensor collectives unavailable)", flush=True)
+        return native
 
     # ---- sharded optimizer ------------------------------------------------------------------------------------
     def _buf(self, key, n, dtype, device):
@@ -56,26 +111,19 @@ class GradReducer:
         return t
 
     def _reduce_scatter(self, out: torch.Tensor, full: torch.Tensor) -> None:
-        """out <- this rank's slice of the SUM over ranks of ``full`` (flat, numel = world * out.numel())."""
+        """out <- this rank's slice of the SUM over ranks of ``full`` (flat, numel = world * out.numel()).
+        The collective was chosen in ``__init__``; an error here propagates (no per-call fallback: see module doc)."""
         if self._native:
-            try:
-                dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=self.group)
-                return
-            except (RuntimeError, AttributeError, NotImplementedError, ValueError, TypeError) as e:   # same arguments on every rank: all fall back
-                print(f"[mfc] reduce_scatter_tensor unavailable ({e}); using all_reduce", flush=True)
-                self._native = False
+            dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=self.group)
+            return
         dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
         out.copy_(full[self.rank * out.numel():(self.rank + 1) * out.numel()])
 
     def _all_gather(self, full: torch.Tensor, mine: torch.Tensor) -> None:
         """full (flat) <- concatenation over ranks of ``mine``; ``mine`` may be this rank's slice of ``full`` (in place)."""
         if self._native:
-            try:
-                dist.all_gather_into_tensor(full, mine, group=self.group)
-                return
-            except (RuntimeError, AttributeError, NotImplementedError, ValueError, TypeError) as e:
-                print(f"[mfc] all_gather_into_tensor unavailable ({e}); using all_gather", flush=True)
-                self._native = False
+            dist.all_gather_into_tensor(full, mine, group=self.group)
+            return
         n = mine.numel()
         if mine.data_ptr() == full[self.rank * n:(self.rank + 1) * n].data_ptr():
             mine = mine.clone()

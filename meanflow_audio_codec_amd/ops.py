@@ -267,27 +267,43 @@ def randn(seed, stream_id, row0, B, D, device="cuda"):
     return out
 
 
-def sample_tr(seed, step, row0, B, Bglobal, mean, std, data_proportion, pair=True, device="cuda"):
+def data_size_of(Bglobal: int, data_proportion: float) -> int:
+    """``data_size = int(batch_size * data_proportion)`` of utils.sample_tr (utils.py:41), in Python double arithmetic
+    like the reference -- the ONE place this integer is computed (kernel and host bookkeeping both take it from here)."""
+    return int(Bglobal * data_proportion)
+
+
+def sample_tr(seed, step, row0, B, Bglobal, mean, std, data_proportion, pair=True, device="cuda", row_stride=1):
+    if row0 < 0 or row_stride < 1 or row0 + (B - 1) * row_stride >= Bglobal:
+        raise ValueError(f"shard rows {row0} + i*{row_stride} (i < {B}) exceed the global batch {Bglobal}")
     t = torch.empty((B, 1), dtype=torch.float32, device=device)
     r = torch.empty((B, 1), dtype=torch.float32, device=device) if pair else None
-    _lib.check(_lib.lib().mfc_sample_tr(seed, step, row0, B, Bglobal, float(mean), float(std),
-                                        float(data_proportion), int(pair), t.data_ptr(), _lib.ptr(r),
+    _lib.check(_lib.lib().mfc_sample_tr(seed, step, row0, row_stride, B, data_size_of(Bglobal, data_proportion),
+                                        float(mean), float(std), int(pair), t.data_ptr(), _lib.ptr(r),
                                         _lib.stream_ptr()), "mfc_sample_tr")
     return t, r
 
 
-def flow_prepare(x, t, dtype, noise_min, noise_max, e=None, seed=0, step=0, row0=0, want_e=False):
-    """z [dtype], target [fp32] (and e if drawn here and want_e)."""
+def flow_prepare(x, t, dtype, noise_min, noise_max, e=None, seed=0, step=0, row0=0, want_e=False, row_stride=1,
+                 out=None):
+    """z [dtype], target [fp32] (and e if drawn here and want_e).  Local row b is global row row0 + b*row_stride of
+    the Philox noise stream.  ``out=(z, target)``: write into these (contiguous row slices are fine)."""
     B, D = x.shape
     assert x.dtype == torch.float32 and x.is_contiguous() and t.numel() == B and t.dtype == torch.float32
-    z = torch.empty((B, D), dtype=dtype, device=x.device)
-    target = torch.empty((B, D), dtype=torch.float32, device=x.device)
+    assert t.is_contiguous()
+    if out is None:
+        z = torch.empty((B, D), dtype=dtype, device=x.device)
+        target = torch.empty((B, D), dtype=torch.float32, device=x.device)
+    else:
+        z, target = out
+        assert z.shape == (B, D) and z.dtype == dtype and z.is_contiguous()
+        assert target.shape == (B, D) and target.dtype == torch.float32 and target.is_contiguous()
     e_out = torch.empty_like(target) if (want_e and e is None) else None
     if e is not None:
         assert e.shape == x.shape and e.dtype == torch.float32 and e.is_contiguous()
     _lib.check(_lib.lib().mfc_flow_prepare(_lib.dtype_code(dtype), B, D, x.data_ptr(), _lib.ptr(e), t.data_ptr(),
-                                           float(noise_min), float(noise_max), seed, step, row0, z.data_ptr(),
-                                           target.data_ptr(), _lib.ptr(e_out), _lib.stream_ptr()),
+                                           float(noise_min), float(noise_max), seed, step, row0, row_stride,
+                                           z.data_ptr(), target.data_ptr(), _lib.ptr(e_out), _lib.stream_ptr()),
                "mfc_flow_prepare")
     return z, target, (e if e is not None else e_out)
 

@@ -14,9 +14,12 @@ Rows whose r == t multiply dudt by exactly 0 (:270), so their v / tangent passes
 (algorithmic 4 F_fwd instead of 5); rows are re-ordered so tangent rows come first.
 
 Extra keyword arguments (not in the reference): ``e, t, r`` to pass the random draws explicitly
-(parity tests), ``row0`` / ``global_batch`` for data-parallel shards (means are over the GLOBAL
-batch and the deterministic "first int(B*p) rows have r = t" rule of utils.sample_tr is applied
-per global row).
+(parity tests), ``row0`` / ``row_stride`` / ``global_batch`` for data-parallel shards: local row i is
+global row ``row0 + i * row_stride`` (means are over the GLOBAL batch and the deterministic "first
+int(B*p) rows have r = t" rule of utils.sample_tr is applied per global row).  Interleaved ownership
+(rank k owns rows k, k+G, ...: ``row0 = k, row_stride = G``) gives every rank the same number of
+r == t rows (+-1), i.e. the same work; contiguous ownership (``row0 = k*B, row_stride = 1``) would give
+the first half of the ranks only r == t rows (3 forward-equivalents) and the rest only tangent rows (5).
 """
 from __future__ import annotations
 
@@ -41,10 +44,13 @@ def _prep_x(x):
     return x.reshape(x.shape[0], -1).contiguous()
 
 
-def _order_rows(t, r, B, row0, Bg, prop, sampled):
+def _order_rows(t, r, B, row0, Bg, prop, sampled, row_stride=1):
     """Permutation putting rows with r != t first; returns (perm | None, n_tan)."""
     if sampled:
-        ds = min(max(int(Bg * prop) - row0, 0), B)      # local rows [0, ds) have r == t
+        # local rows i with row0 + i*row_stride < data_size have r == t: a local prefix [0, ds).  data_size is the
+        # SAME integer the kernel received (ops.data_size_of; ADVICE r1: the kernel used to recompute it in float).
+        gsz = ops.data_size_of(Bg, prop)
+        ds = min(max(-((row0 - gsz) // row_stride), 0), B)   # ceil((gsz - row0) / row_stride), clamped
         if ds == 0:
             return None, B
         if ds == B:
@@ -70,17 +76,19 @@ class FlowMatchingLoss(LossStrategy):
         self.time_sampling = time_sampling or LogitNormalTimeSampling()
         self.use_weighted_loss = use_weighted_loss
 
-    def compute_loss(self, state, key, x, *, e=None, t=None, row0=0, global_batch=None, aux=None, on_block=None, fused=None):
+    def compute_loss(self, state, key, x, *, e=None, t=None, row0=0, global_batch=None, aux=None, on_block=None,
+                     fused=None, row_stride=1):
         model, w = state.model, state.work
         x = _prep_x(x)
         B = x.shape[0]
         Bg = global_batch or B
         if t is None:
-            t = self.time_sampling.sample_time(key, B, row0=row0, global_batch=Bg, device=x.device)
+            t = self.time_sampling.sample_time(key, B, row0=row0, global_batch=Bg, device=x.device,
+                                               row_stride=row_stride)
         t = t.reshape(B, 1).float().contiguous()
         ns = self.noise_schedule
         z, target, _ = ops.flow_prepare(x, t, model.dtype, ns.noise_min, ns.noise_max, e=e, seed=key.seed,
-                                        step=key.counter, row0=row0)
+                                        step=key.counter, row0=row0, row_stride=row_stride)
         ctx_holder = model.new_ctx()
         latents = model.encode(w, x, ctx_holder)
         cond, _ = model.conditioning(w, t, torch.zeros_like(t), latents)
@@ -98,23 +106,41 @@ class _TwoTimeLoss(LossStrategy):
     kind = 0
 
     def _run(self, state, key, x, e, t, r, row0, global_batch, aux, *, nmin, nmax, mode, p, c, use_v_pass,
-             on_block=None, fused=None):
+             on_block=None, fused=None, row_stride=1):
         model, w = state.model, state.work
         x = _prep_x(x)
         B = x.shape[0]
         Bg = global_batch or B
         sampled = t is None
         if sampled:
-            t, r = self.time_sampling.sample_time_pair(key, B, row0=row0, global_batch=Bg, device=x.device)
+            t, r = self.time_sampling.sample_time_pair(key, B, row0=row0, global_batch=Bg, device=x.device,
+                                                       row_stride=row_stride)
         t = t.reshape(B, 1).float().contiguous()
         r = r.reshape(B, 1).float().contiguous()
-        perm, n_tan = _order_rows(t, r, B, row0, Bg, getattr(self.time_sampling, "data_proportion", 0.5), sampled)
-        if perm is not None:
+        perm, n_tan = _order_rows(t, r, B, row0, Bg, getattr(self.time_sampling, "data_proportion", 0.5), sampled,
+                                  row_stride)
+        prep = dict(seed=key.seed, step=key.counter)
+        if perm is None:
+            z, target, _ = ops.flow_prepare(x, t, model.dtype, nmin, nmax, e=e, row0=row0, row_stride=row_stride, **prep)
+        elif e is not None:
+            x, t, r, e = x[perm].contiguous(), t[perm].contiguous(), r[perm].contiguous(), e[perm].contiguous()
+            z, target, _ = ops.flow_prepare(x, t, model.dtype, nmin, nmax, e=e, **prep)
+        elif sampled:
+            # the permutation is the rotation [ds, B) ++ [0, ds): two launches keep the Philox noise keyed by the
+            # GLOBAL row each sample had before the re-ordering (shards then sum to the full batch exactly)
+            ds = B - n_tan
             x, t, r = x[perm].contiguous(), t[perm].contiguous(), r[perm].contiguous()
-            if e is not None:
-                e = e[perm].contiguous()
-        z, target, _ = ops.flow_prepare(x, t, model.dtype, nmin, nmax, e=e, seed=key.seed, step=key.counter,
-                                        row0=row0)
+            z = torch.empty((B, x.shape[1]), dtype=model.dtype, device=x.device)
+            target = torch.empty((B, x.shape[1]), dtype=torch.float32, device=x.device)
+            ops.flow_prepare(x[:n_tan], t[:n_tan], model.dtype, nmin, nmax, row0=row0 + ds * row_stride,
+                             row_stride=row_stride, out=(z[:n_tan], target[:n_tan]), **prep)
+            ops.flow_prepare(x[n_tan:], t[n_tan:], model.dtype, nmin, nmax, row0=row0, row_stride=row_stride,
+                             out=(z[n_tan:], target[n_tan:]), **prep)
+        else:
+            # explicit (t, r) with an arbitrary r == t pattern and no explicit noise: draw in the original order, permute
+            z, target, _ = ops.flow_prepare(x, t, model.dtype, nmin, nmax, row0=row0, row_stride=row_stride, **prep)
+            x, t, r = x[perm].contiguous(), t[perm].contiguous(), r[perm].contiguous()
+            z, target = z[perm].contiguous(), target[perm].contiguous()
         ctx_holder = model.new_ctx()
         latents = model.encode(w, x, ctx_holder)
         h = ops.axpby(1.0, t, -1.0, r)
@@ -156,9 +182,10 @@ class MeanFlowLoss(_TwoTimeLoss):
         self.c = c
 
     def compute_loss(self, state, key, x, *, e=None, t=None, r=None, row0=0, global_batch=None, aux=None,
-                     on_block=None, fused=None):
+                     on_block=None, fused=None, row_stride=1):
         return self._run(state, key, x, e, t, r, row0, global_batch, aux, nmin=0.0, nmax=1.0, mode=2,
-                         p=1.0 - self.gamma, c=self.c, use_v_pass=False, on_block=on_block, fused=fused)
+                         p=1.0 - self.gamma, c=self.c, use_v_pass=False, on_block=on_block, fused=fused,
+                         row_stride=row_stride)
 
 
 class ImprovedMeanFlowLoss(_TwoTimeLoss):
@@ -172,7 +199,8 @@ class ImprovedMeanFlowLoss(_TwoTimeLoss):
         self.use_weighted_loss = use_weighted_loss
 
     def compute_loss(self, state, key, x, *, e=None, t=None, r=None, row0=0, global_batch=None, aux=None,
-                     on_block=None, fused=None):
+                     on_block=None, fused=None, row_stride=1):
         ns = self.noise_schedule
         return self._run(state, key, x, e, t, r, row0, global_batch, aux, nmin=ns.noise_min, nmax=ns.noise_max,
-                         mode=_loss_mode(self.use_weighted_loss), p=1.0, c=1e-3, use_v_pass=True, on_block=on_block, fused=fused)
+                         mode=_loss_mode(self.use_weighted_loss), p=1.0, c=1e-3, use_v_pass=True, on_block=on_block,
+                         fused=fused, row_stride=row_stride)

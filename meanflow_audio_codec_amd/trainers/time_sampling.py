@@ -31,15 +31,19 @@ class PRNGKey:
 class TimeSamplingStrategy(ABC):
     @abstractmethod
     def sample_time(self, key: PRNGKey, batch_size: int, dtype=torch.float32, row0: int = 0,
-                    global_batch: int | None = None, device="cuda") -> torch.Tensor:
+                    global_batch: int | None = None, device="cuda", row_stride: int = 1) -> torch.Tensor:
+        """``row0`` / ``row_stride`` / ``global_batch``: local row i is global row ``row0 + i * row_stride`` of a
+        batch of ``global_batch`` (data-parallel shards draw the rows of the global batch they own)."""
         ...
 
 
 class UniformTimeSampling(TimeSamplingStrategy):
     """t ~ U[0,1] (time_sampling.py:39-49) -- host-side torch.rand is not used: Philox normal -> Phi."""
-    def sample_time(self, key, batch_size, dtype=torch.float32, row0=0, global_batch=None, device="cuda"):
-        n = ops.randn(key.seed ^ 0x5EED, 0x7500 + (key.counter & 0xFFFF), row0, batch_size, 1, device=device)
-        return (0.5 * (1.0 + torch.erf(n / 2.0 ** 0.5))).to(dtype)
+    def sample_time(self, key, batch_size, dtype=torch.float32, row0=0, global_batch=None, device="cuda", row_stride=1):
+        Bg = global_batch or batch_size
+        n = ops.randn(key.seed ^ 0x5EED, 0x7500 + (key.counter & 0xFFFF), 0, Bg, 1, device=device)
+        n = n[row0:row0 + (batch_size - 1) * row_stride + 1:row_stride]
+        return (0.5 * (1.0 + torch.erf(n / 2.0 ** 0.5))).to(dtype).contiguous()
 
 
 class LogitNormalTimeSampling(TimeSamplingStrategy):
@@ -48,9 +52,9 @@ class LogitNormalTimeSampling(TimeSamplingStrategy):
         self.mean = mean
         self.std = std
 
-    def sample_time(self, key, batch_size, dtype=torch.float32, row0=0, global_batch=None, device="cuda"):
+    def sample_time(self, key, batch_size, dtype=torch.float32, row0=0, global_batch=None, device="cuda", row_stride=1):
         t, _ = ops.sample_tr(key.seed, key.counter, row0, batch_size, global_batch or batch_size, self.mean,
-                             self.std, 0.0, pair=False, device=device)
+                             self.std, 0.0, pair=False, device=device, row_stride=row_stride)
         return t
 
 
@@ -61,11 +65,12 @@ class MeanFlowTimeSampling(TimeSamplingStrategy):
         self.std = std
         self.data_proportion = data_proportion
 
-    def sample_time(self, key, batch_size, dtype=torch.float32, row0=0, global_batch=None, device="cuda"):
+    def sample_time(self, key, batch_size, dtype=torch.float32, row0=0, global_batch=None, device="cuda", row_stride=1):
         t, _ = ops.sample_tr(key.seed, key.counter, row0, batch_size, global_batch or batch_size, self.mean,
-                             self.std, self.data_proportion, pair=False, device=device)
+                             self.std, self.data_proportion, pair=False, device=device, row_stride=row_stride)
         return t
 
-    def sample_time_pair(self, key, batch_size, dtype=torch.float32, row0=0, global_batch=None, device="cuda"):
+    def sample_time_pair(self, key, batch_size, dtype=torch.float32, row0=0, global_batch=None, device="cuda",
+                         row_stride=1):
         return ops.sample_tr(key.seed, key.counter, row0, batch_size, global_batch or batch_size, self.mean,
-                             self.std, self.data_proportion, pair=True, device=device)
+                             self.std, self.data_proportion, pair=True, device=device, row_stride=row_stride)

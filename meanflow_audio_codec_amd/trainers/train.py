@@ -270,7 +270,8 @@ def train_flow(config, data_iterator=None, *, resume: bool = False, n_steps: int
         B = x.shape[0]
         if tokenization is not None:
             x = tokenization.tokenize(x).reshape(B, -1)
-        state, loss, key = train_step(state, key, x, strategy, reducer=reducer, row0=rank * B,
+        # data parallel: this rank's batch holds global rows rank, rank + world, ... (distributed.shard_rows)
+        state, loss, key = train_step(state, key, x, strategy, reducer=reducer, row0=rank, row_stride=world,
                                       global_batch=world * B)
         loss_val = float(loss)                         # device sync, as trainers/train.py:347
         loss_avg = loss_val if loss_avg is None else 0.99 * loss_avg + 0.01 * loss_val   # utils.ema :28-29

@@ -33,26 +33,28 @@ def _side_stream(device):
     return s
 
 
-def _fused_step(state, key, x, loss_strategy, row0, global_batch):
+def _fused_step(state, key, x, loss_strategy, row0, global_batch, row_stride=1):
     """Single-GPU schedule: no gradient exchange sits between the reverse pass and the optimizer, so the big kernels
     are updated by the epilogue of their own weight-gradient product (``mfc_gemm_adamw``: the bf16 gradient is never
     written or re-read) and only the remaining leaves go through ``mfc_adamw``.  The fused kernel is bit-identical to
     gemm -> adamw; whole steps agree with the sequential schedule up to the run-to-run noise of the fp32-atomic sums."""
     state.begin_update()
     fused = state.fused_updater()
-    loss, grads = loss_strategy.compute_loss(state, key, x, row0=row0, global_batch=global_batch, fused=fused)
+    loss, grads = loss_strategy.compute_loss(state, key, x, row0=row0, global_batch=global_batch, fused=fused,
+                                            row_stride=row_stride)
     state.apply_subset([k for k in state.params if k not in fused.done], grads)
     return state, loss, key.next()
 
 
 def _train_step_with_strategy(state, key, x, loss_strategy: LossStrategy, *, reducer=None, row0=0,
-                              global_batch=None, overlap=True, fuse=None):
+                              global_batch=None, overlap=True, fuse=None, row_stride=1):
     if fuse is None:
         fuse = reducer is None and x.is_cuda
     if fuse and reducer is None and x.is_cuda:
-        return _fused_step(state, key, x, loss_strategy, row0, global_batch)
+        return _fused_step(state, key, x, loss_strategy, row0, global_batch, row_stride)
     if not overlap or not x.is_cuda:
-        loss, grads = loss_strategy.compute_loss(state, key, x, row0=row0, global_batch=global_batch)
+        loss, grads = loss_strategy.compute_loss(state, key, x, row0=row0, global_batch=global_batch,
+                                                row_stride=row_stride)
         if reducer is not None and reducer.shard_optimizer:
             state.begin_update()
             defer = [] if reducer.defer_gather else None
@@ -90,7 +92,8 @@ def _train_step_with_strategy(state, key, x, loss_strategy: LossStrategy, *, red
             state.apply_subset(rest, grads_ref)
         done.update(names)
 
-    loss, grads = loss_strategy.compute_loss(state, key, x, row0=row0, global_batch=global_batch, on_block=on_block)
+    loss, grads = loss_strategy.compute_loss(state, key, x, row0=row0, global_batch=global_batch, on_block=on_block,
+                                            row_stride=row_stride)
     rest = [k for k in state.params if k not in done]
     if rest:
         on_block(rest)
@@ -108,9 +111,11 @@ def _train_step_with_strategy(state, key, x, loss_strategy: LossStrategy, *, red
 
 
 def train_step(state, key, x, loss_strategy: LossStrategy | None = None, *, reducer=None, row0=0,
-               global_batch=None, overlap=True, fuse=None):
-    """``fuse``: None = the fused single-GPU schedule whenever there is no reducer (``overlap`` then has no effect)."""
+               global_batch=None, overlap=True, fuse=None, row_stride=1):
+    """``fuse``: None = the fused single-GPU schedule whenever there is no reducer (``overlap`` then has no effect).
+    Data parallel: local row i of ``x`` is global row ``row0 + i * row_stride`` of a batch of ``global_batch``
+    (``distributed.shard_rows(rank, world, B)`` gives the interleaved layout rank k -> rows k, k+G, ...)."""
     if loss_strategy is None:
         loss_strategy = FlowMatchingLoss()
     return _train_step_with_strategy(state, key, x, loss_strategy, reducer=reducer, row0=row0,
-                                     global_batch=global_batch, overlap=overlap, fuse=fuse)
+                                     global_batch=global_batch, overlap=overlap, fuse=fuse, row_stride=row_stride)

@@ -15,6 +15,29 @@ def test_library_builds_and_exports_header_symbols():
     assert set(_lib.SIGNATURES) == set(declared)
 
 
+def test_header_and_ctypes_signatures_agree():
+    """Argument count and C type class (pointer / integer width / float) of every declaration in include/mfc.h
+    against the ctypes signature the Python side binds it with."""
+    import re
+    txt = re.sub(r"/\*.*?\*/", "", _lib.HEADER.read_text(), flags=re.S)
+    kinds = {ctypes.c_void_p: "ptr", ctypes.c_char_p: "ptr", ctypes.c_int: "int", ctypes.c_int64: "int64_t",
+             ctypes.c_uint64: "uint64_t", ctypes.c_float: "float", ctypes.c_double: "double"}
+    seen = 0
+    for m in re.finditer(r"\b(mfc_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+        name, args = m.group(1), " ".join(m.group(2).split())
+        decl = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        sig = _lib.SIGNATURES[name][1]
+        assert len(sig) == len(decl), (name, decl, sig)
+        for d, ty in zip(decl, sig):
+            want = kinds[ty]
+            if "*" in d:
+                assert want == "ptr", (name, d, ty)
+            else:
+                assert d.split()[-2] == want or (want == "int" and d.split()[-2] in ("int", "unsigned")), (name, d, ty)
+        seen += 1
+    assert seen == len(_lib.SIGNATURES)
+
+
 def test_no_gpu_entry_points():
     l = _lib.lib()
     assert l.mfc_abi_version() >= 1

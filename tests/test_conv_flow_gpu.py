@@ -172,6 +172,45 @@ def test_data_parallel_shards_sum_to_global_batch():
             assert ((acc[k] - full[k]).abs().max() / full[k].abs().max()).item() < 2e-3, k
 
 
+@pytest.mark.parametrize("world,prop", [(2, 0.5), (4, 0.5), (2, 0.7)])
+def test_interleaved_shards_sum_to_global_batch_sampled(world, prop):
+    """The SAMPLED path ((e, t, r) drawn from Philox inside the step) under the interleaved ownership of
+    distributed.shard_rows (rank k owns global rows k, k+G, ...): shard losses and gradients sum to the
+    full-batch step, every shard sees the same number (+-1) of r == t rows, and (t != r).sum() == n_tan with
+    data_size = int(B * p) computed once on the host (B*p integer with p not exact in f32)."""
+    from meanflow_audio_codec_amd.distributed import shard_of, shard_rows
+    from meanflow_audio_codec_amd.trainers import ImprovedMeanFlowLoss, MeanFlowTimeSampling, PRNGKey
+    model, state, pq = _make(torch.float32, seed=11)
+    Bg = 10 if prop == 0.7 else 8
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(Bg, D, generator=g).cuda()
+    strat = ImprovedMeanFlowLoss(time_sampling=MeanFlowTimeSampling(-0.4, 1.0, prop))
+    key = PRNGKey(7, 3)
+    aux = {}
+    loss_full, grads = strat.compute_loss(state, key, x, aux=aux)
+    assert aux["n_tan"] == Bg - int(Bg * prop) == int((aux["t"] != aux["r"]).sum().item())
+    full = {k: v.double().clone() for k, v in grads.items()}
+    acc = {k: torch.zeros_like(v) for k, v in full.items()}
+    loss_sum, n_tans = 0.0, []
+    if Bg % world:
+        pytest.skip("global batch not divisible")
+    for rank in range(world):
+        a = {}
+        l, gr = strat.compute_loss(state, key, shard_of(x, rank, world), aux=a, **shard_rows(rank, world, Bg // world))
+        # the shard drew exactly the (t, r) of the global rows it owns
+        assert torch.equal(a["t"], aux["t"][rank::world]) and torch.equal(a["r"], aux["r"][rank::world])
+        assert a["n_tan"] == int((a["t"] != a["r"]).sum().item())
+        n_tans.append(a["n_tan"])
+        loss_sum += l.item()
+        for k in acc:
+            acc[k] += gr[k].double()
+    assert max(n_tans) - min(n_tans) <= 1 and sum(n_tans) == aux["n_tan"], n_tans
+    assert abs(loss_sum - loss_full.item()) < 1e-5
+    for k in full:
+        if full[k].abs().max() > 0:
+            assert ((acc[k] - full[k]).abs().max() / full[k].abs().max()).item() < 2e-3, k
+
+
 def test_overlapped_train_step_matches_sequential():
     """overlap=True (per-block AdamW on a side stream during the reverse pass) == overlap=False (up to the
     run-to-run noise of the fp32-atomic small-parameter gradients)."""

@@ -31,12 +31,13 @@ def _run(rank, world, shard, overlap, steps=2):
     flat = {k: v.float().cuda().contiguous() for k, v in fo.flatten(p64).items()}
     state = TrainState.create(apply_fn=model.apply, params=flat, tx=adamw(1e-3, 1e-2), model=model)
     g = torch.Generator().manual_seed(5)
-    x = torch.randn(world * B, D, generator=g)[rank * B:(rank + 1) * B].cuda()
+    from meanflow_audio_codec_amd.distributed import shard_of, shard_rows
+    x = shard_of(torch.randn(world * B, D, generator=g), rank, world).cuda()     # interleaved ownership
     red = GradReducer(small_numel=1 << 12, shard_optimizer=shard)
     key = PRNGKey(3)
     for _ in range(steps):
-        state, loss, key = train_step(state, key, x, ImprovedMeanFlowLoss(), reducer=red, row0=rank * B,
-                                      global_batch=world * B, overlap=overlap)
+        state, loss, key = train_step(state, key, x, ImprovedMeanFlowLoss(), reducer=red, overlap=overlap,
+                                      **shard_rows(rank, world, B))
     # deferred gathers: every sharded leaf of the last step has an event waiting for its first reader
     assert len(state.work.pending) == (len(red.sharded) if red.defer_gather else 0)
     torch.cuda.synchronize()

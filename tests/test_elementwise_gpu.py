@@ -32,6 +32,21 @@ def test_sample_tr_rule_and_sharding():
     assert torch.equal(torch.cat([ta, tb]), t) and torch.equal(torch.cat([ra, rb]), r)
     t2, _ = ops.sample_tr(42, 4, 0, 64, 64, -0.4, 1.0, 0.5)
     assert not torch.equal(t, t2)          # the step advances the stream (reference defect 4 fixed)
+    # interleaved shards (distributed.shard_rows: rank k owns rows k, k+G, ...) reproduce it too
+    for G in (2, 4, 8):
+        for k in range(G):
+            tk, rk = ops.sample_tr(42, 3, k, 64 // G, 64, -0.4, 1.0, 0.5, row_stride=G)
+            assert torch.equal(tk, t[k::G]) and torch.equal(rk, r[k::G])
+            assert int((tk == rk).sum().item()) == 32 // G       # every rank gets the same share of r == t rows
+    # data_size = int(B * p) in host double arithmetic (utils.py:41) -- cases where float32(p) * B lands below the
+    # integer (the kernel used to recompute it: 69 instead of 70 for B=100, p=0.7)
+    for B, prop in ((100, 0.7), (10, 0.7), (10, 0.9), (50, 0.9), (200, 0.7), (64, 0.5), (7, 0.0), (7, 1.0)):
+        tt, rr = ops.sample_tr(5, 1, 0, B, B, -0.4, 1.0, prop)
+        ds = int(B * prop)
+        assert ops.data_size_of(B, prop) == ds
+        assert int((tt == rr).sum().item()) == ds and torch.equal(tt[:ds], rr[:ds]) and (tt[ds:] > rr[ds:]).all()
+    with pytest.raises(ValueError):
+        ops.sample_tr(1, 0, 60, 8, 64, -0.4, 1.0, 0.5)          # rows 60..67 exceed the global batch
     # logit-normal(-0.4, 1): median sigmoid(-0.4)
     tl, _ = ops.sample_tr(1, 0, 0, 20000, 20000, -0.4, 1.0, 0.5, pair=False)
     assert abs(tl.median().item() - 1 / (1 + math.exp(0.4))) < 0.01
