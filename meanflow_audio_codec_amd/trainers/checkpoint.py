@@ -284,7 +284,23 @@ def read_tree(f: BinaryIO):
 def restore_into(f: BinaryIO, targets: dict) -> dict:
     """Stream a checkpoint into preallocated tensors: ``targets`` maps a state-dict path ("params/blocks_0/...",
     "opt_state/0/mu/...") to the torch tensor to fill (any device).  Returns the non-array leaves ({"step": ...})
-    and raises on missing / unexpected / mis-shaped leaves."""
+    and raises on missing / unexpected / mis-shaped leaves.
+
+    Two passes over the file: the first walks the whole tree checking keys, shapes, dtypes and payload lengths against
+    the file size while SEEKING over the payloads (no bytes read, nothing written); only when it succeeds does the
+    second pass copy into ``targets``.  A truncated file or a tree that does not match the template therefore leaves
+    the template untouched -- like the reference's functional ``serialization.from_bytes`` (trainers/utils.py:53-58),
+    whose template is never modified by a failed load."""
+    start = f.tell()
+    f.seek(0, 2)
+    end = f.tell()
+    f.seek(start)
+    _restore_pass(f, targets, dry=True, end=end)
+    f.seek(start)
+    return _restore_pass(f, targets, dry=False, end=end)
+
+
+def _restore_pass(f: BinaryIO, targets: dict, dry: bool, end: int) -> dict:
     seen: set = set()
     scalars: dict = {}
     path: list = []
@@ -295,8 +311,13 @@ def restore_into(f: BinaryIO, targets: dict) -> dict:
             raise ValueError(f"dtype mismatch at {'/'.join(path)}: checkpoint {name}, state {want}")
         n = nbytes // dst.element_size()
         flat = dst.reshape(-1)
-        if lo + n > flat.numel():
+        if lo + n > flat.numel() or nbytes % dst.element_size():
             raise ValueError(f"size mismatch at {'/'.join(path)}")
+        if reader.f.tell() + nbytes > end:
+            raise ValueError("truncated msgpack stream")
+        if dry:
+            reader.f.seek(nbytes, 1)
+            return n
         step = max(1, (256 << 20) // dst.element_size())
         for o in range(0, n, step):
             m = min(step, n - o)

@@ -108,6 +108,69 @@ def test_mismatches_raise_value_error(tmp_path):
         ck.load_checkpoint(p, _State())
 
 
+def _snapshot(st):
+    return ({k: v.clone() for k, v in st.params.items()}, {k: v.clone() for k, v in st.opt_state["mu"].items()},
+            {k: v.clone() for k, v in st.opt_state["nu"].items()}, st.step, st.refreshed)
+
+
+def _same(st, snap):
+    return (all(torch.equal(st.params[k], snap[0][k]) for k in snap[0]) and
+            all(torch.equal(st.opt_state["mu"][k], snap[1][k]) for k in snap[1]) and
+            all(torch.equal(st.opt_state["nu"][k], snap[2][k]) for k in snap[2]) and
+            st.step == snap[3] and st.refreshed == snap[4])
+
+
+@pytest.mark.parametrize("chunk", [2 ** 30, 24])
+def test_failed_load_leaves_the_template_untouched(tmp_path, monkeypatch, chunk):
+    """a failed load must not leave the template partly overwritten (train_flow would then 'start from
+    scratch' on a hybrid state).  The loader validates the whole file against the template before its first write."""
+    monkeypatch.setattr(ck, "MAX_CHUNK_BYTES", chunk, raising=False)
+    src = _State(seed=3, step=30)
+    p = tmp_path / "checkpoints" / "step_00030.msgpack"
+    ck.save_checkpoint(p, src)
+    raw = p.read_bytes()
+    # (a) truncated at several depths: some leaves complete in the file, later ones cut
+    for cut in (len(raw) - 1, len(raw) - 40, len(raw) // 2, len(raw) // 3):
+        p.write_bytes(raw[:cut])
+        tmpl = _State(seed=5, step=0)
+        snap = _snapshot(tmpl)
+        with pytest.raises(ValueError):
+            ck.load_checkpoint(p, tmpl)
+        assert _same(tmpl, snap), cut
+    # (b) a mismatching LATE leaf (the tree is written in sorted key order: params < opt_state is not the file order,
+    # so make the mismatch the last leaf of the params subtree)
+    p.write_bytes(raw)
+    tmpl = _State(seed=5, step=0)
+    tmpl.params["latent_proj/kernel"] = torch.zeros(3, 5)
+    snap = _snapshot(tmpl)
+    with pytest.raises(ValueError, match="shape mismatch"):
+        ck.load_checkpoint(p, tmpl)
+    assert _same(tmpl, snap)
+    # (c) dtype mismatch
+    tmpl = _State(seed=5, step=0)
+    tmpl.opt_state["nu"]["latent_proj/kernel"] = tmpl.opt_state["nu"]["latent_proj/kernel"].bfloat16()
+    snap = _snapshot(tmpl)
+    with pytest.raises(ValueError, match="dtype mismatch"):
+        ck.load_checkpoint(p, tmpl)
+    assert _same(tmpl, snap)
+    # (d) resume: newest truncated, older one of a DIFFERENT architecture -> nothing loads, template bit-equal to fresh
+    other = _State(seed=9, step=20, n=6)
+    ck.save_checkpoint(tmp_path / "checkpoints" / "step_00020.msgpack", other)
+    p.write_bytes(raw[:len(raw) // 2])
+    tmpl = _State(seed=5, step=0)
+    snap = _snapshot(tmpl)
+    with pytest.raises(FileNotFoundError):
+        ck.load_checkpoint_and_resume(tmp_path, tmpl)
+    assert _same(tmpl, snap)
+    # and the intact file still loads completely
+    p.write_bytes(raw)
+    tmpl = _State(seed=5, step=0)
+    st = ck.load_checkpoint(p, tmpl)
+    assert st.step == 30 and st.refreshed == 1
+    assert all(torch.equal(st.params[k], src.params[k]) for k in src.params)
+    assert all(torch.equal(st.opt_state["nu"][k], src.opt_state["nu"][k]) for k in src.params)
+
+
 def test_management_resume_and_cleanup(tmp_path):
     class Cfg:
         def to_dict(self):

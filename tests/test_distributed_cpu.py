@@ -120,3 +120,39 @@ def test_use_order_and_workdict_without_gpu():
     assert w.pending == {} and torch.equal(w["a"], torch.ones(2)) and w.get("b") is None and w.get("a") is w["a"]
     w.wait_all()                       # nothing pending: no device call
     assert list(w) == ["a"] and len(w) == 1
+
+
+def test_interleaved_row_ownership_balances_the_rt_rule():
+    """distributed.shard_rows + loss_strategies._order_rows: under interleaved ownership every rank holds the same
+    number (+-1) of global rows below data_size = int(B*p) (utils.py:41-44), as a LOCAL PREFIX, and the shards
+    partition the global batch.  Pure host arithmetic (no GPU)."""
+    from meanflow_audio_codec_amd import ops
+    from meanflow_audio_codec_amd.distributed import shard_of, shard_rows
+    from meanflow_audio_codec_amd.trainers.loss_strategies import _order_rows
+    for Bg, prop in ((128, 0.5), (128, 0.7), (100, 0.7), (16, 0.9), (8, 0.0), (8, 1.0), (24, 0.3)):
+        gsz = ops.data_size_of(Bg, prop)
+        assert gsz == int(Bg * prop)
+        for G in (1, 2, 4, 8):
+            if Bg % G:
+                continue
+            B = Bg // G
+            glob = torch.arange(Bg)
+            seen, n_rt = [], []
+            for k in range(G):
+                kw = shard_rows(k, G, B)
+                assert kw == dict(row0=k, row_stride=G, global_batch=Bg)
+                mine = shard_of(glob, k, G)
+                assert torch.equal(mine, k + G * torch.arange(B))
+                seen.append(mine)
+                t = torch.zeros(B, 1)
+                perm, n_tan = _order_rows(t, t, B, kw["row0"], Bg, prop, True, kw["row_stride"])
+                ds = B - n_tan
+                assert ds == int((mine < gsz).sum()) and bool((mine[:ds] < gsz).all()) and bool((mine[ds:] >= gsz).all())
+                if perm is not None:          # tangent rows first, then the r == t rows, original order inside each
+                    assert torch.equal(perm, torch.cat([torch.arange(ds, B), torch.arange(0, ds)]))
+                n_rt.append(ds)
+            assert sum(n_rt) == gsz and max(n_rt) - min(n_rt) <= 1, (Bg, prop, G, n_rt)
+            assert torch.equal(torch.sort(torch.cat(seen)).values, glob)
+        # contiguous ownership (row_stride 1), still supported: prefix rule per global row
+        perm, n_tan = _order_rows(torch.zeros(4, 1), torch.zeros(4, 1), 4, Bg - 4, Bg, prop, True, 1)
+        assert 4 - n_tan == max(0, min(4, gsz - (Bg - 4)))
