@@ -10,7 +10,15 @@ pinned by
 
 * the reference's own property tests, restated in ``tests/test_oracle_flow.py``
   (``test/test_improved_mean_flow.py:31-54`` boundary condition t=r => v_pred==u,
-  ``:57-100`` forward-mode JVP == reverse-mode directional derivative), and
+  ``:57-100`` forward-mode JVP == reverse-mode directional derivative),
+* numbers the reference itself produced: its PyTorch implementations
+  ``references/archive/{flow,mflow,imflow}.py`` DO import here and were run by
+  ``tests/golden/gen_archive_flow_golden.py``; the loss / sampler CORES below
+  (``fm_core``, ``mf_core``, ``imf_core``, ``heun_integrate``, ``heun_two_time``) are the single
+  implementation used both by the JAX-path restatements (``fm_loss``, ``mf_loss``, ``imf_loss``,
+  ``heun_sample``) and by the archive-net variants that ``tests/test_oracle_archive.py`` compares with those
+  fixtures (loss, every gradient, u, du/dt, samples) -- so interpolation, targets, JVP tangents, stop-gradient
+  placement, the adaptive weight and the Heun integrator are PINNED, and
 * hand-derived closed forms for the small ops (LayerNorm, GRN, GELU, AdamW).
 
 Initialiser, optimizer-update and PRNG parity with Flax/optax/JAX are UNPINNED
@@ -393,6 +401,37 @@ def _req(params):
     return tree_map(lambda v: v.detach().clone().requires_grad_(True), params)
 
 
+def imf_core(u_fn, v, z, t, r, tangent="t"):
+    """The improved-MeanFlow compound prediction, shared by the JAX-path restatement and the archive variant.
+    ``u_fn(z, t, r) -> u``; JVP of u along (v, tdot, rdot): ``tangent="t"`` is (v, 1, 0)
+    (trainers/loss_strategies.py:263-267), ``tangent="r"`` is (v, 0, 1) (references/archive/imflow.py:152-155).
+    du/dt is stop-gradient (loss_strategies.py:270 / imflow.py:158 ``dudt.detach()``);
+    V = u + (t - r) sg(du/dt).  Returns (u, dudt, V)."""
+    one, zero = torch.ones_like(t), torch.zeros_like(t)
+    tang = (v, one, zero) if tangent == "t" else (v, zero, one)
+    u, dudt = torch.func.jvp(u_fn, (z, t, r), tang)
+    dudt = dudt.detach()
+    return u, dudt, u + (t - r) * dudt
+
+
+def mf_core(u_fn, z, t, r, v, gamma=0.5, c=1e-3):
+    """MeanFlow loss core (trainers/loss_strategies.py:177-198 == references/archive/mflow.py:143-150):
+    JVP tangent (v, 1, 0) with v = e - x, u_tgt = v - clip(t-r, 0, 1) du/dt, stop-gradient on the whole target,
+    per-example MEAN squared error, weight sg(1/(d + c)^(1-gamma)).  Returns (loss, u, dudt)."""
+    u, dudt = torch.func.jvp(u_fn, (z, t, r), (v, torch.ones_like(t), torch.zeros_like(r)))
+    u_tgt = v - torch.clamp(t - r, 0.0, 1.0) * dudt
+    err = u - u_tgt.detach()
+    dsq = (err ** 2).flatten(1).mean(1)
+    w = (1.0 / (dsq + c) ** (1.0 - gamma)).detach()
+    return (w * dsq).mean(), u, dudt
+
+
+def fm_core(f, x, e, t, noise_min=0.001, noise_max=0.999):
+    """Flow-matching pieces (trainers/loss_strategies.py:98-106 with LinearNoiseSchedule ==
+    references/archive/flow.py:107-113): (pred, target) with pred = f(z, t)."""
+    return f(linear_interpolate(x, e, t, noise_min, noise_max), t), linear_target(x, e, noise_max)
+
+
 def imf_parts(apply, encode, params, x, e, t, r, noise_min=0.001, noise_max=0.999):
     """ImprovedMeanFlowLoss.compute_loss pieces, trainers/loss_strategies.py:227-277.
     Returns (v, u, dudt, v_pred, target) -- dudt already detached."""
@@ -404,9 +443,7 @@ def imf_parts(apply, encode, params, x, e, t, r, noise_min=0.001, noise_max=0.99
     def u_fn(z_, t_, r_):
         return apply(params, z_, torch.cat([t_, t_ - r_], -1), latents)
 
-    u, dudt = torch.func.jvp(u_fn, (z, t, r), (v, torch.ones_like(t), torch.zeros_like(r)))
-    dudt = dudt.detach()
-    v_pred = u + (t - r) * dudt
+    u, dudt, v_pred = imf_core(u_fn, v, z, t, r, tangent="t")
     return v, u, dudt, v_pred, target
 
 
@@ -422,12 +459,12 @@ def fm_loss(apply, encode, params, x, e, t, use_weighted_loss=True, noise_min=0.
             schedule="linear"):
     """FlowMatchingLoss.compute_loss, trainers/loss_strategies.py:73-112."""
     params = _req(params)
-    if schedule == "linear":
-        z, target = linear_interpolate(x, e, t, noise_min, noise_max), linear_target(x, e, noise_max)
-    else:  # UniformNoiseSchedule, trainers/noise_schedules.py:91-115
-        z, target = (1.0 - t) * x + t * e, e - x
     latents = encode(params, x) if encode is not None else None
-    pred = apply(params, z, torch.cat([t, torch.zeros_like(t)], -1), latents)
+    f = lambda z_, t_: apply(params, z_, torch.cat([t_, torch.zeros_like(t_)], -1), latents)
+    if schedule == "linear":
+        pred, target = fm_core(f, x, e, t, noise_min, noise_max)
+    else:  # UniformNoiseSchedule, trainers/noise_schedules.py:91-115
+        pred, target = fm_core(f, x, e, t, 0.0, 1.0)
     loss = weighted_l2_loss(pred, target) if use_weighted_loss else ((pred - target) ** 2).mean()
     return loss.detach(), _grads(loss, params), dict(pred=pred.detach())
 
@@ -442,12 +479,7 @@ def mf_loss(apply, encode, params, x, e, t, r, gamma=0.5, c=1e-3):
     def u_fn(z_, t_, r_):
         return apply(params, z_, torch.cat([t_, t_ - r_], -1), latents)
 
-    u, dudt = torch.func.jvp(u_fn, (z, t, r), (target, torch.ones_like(t), torch.zeros_like(r)))
-    u_tgt = target - torch.clamp(t - r, 0.0, 1.0) * dudt.detach()
-    err = u - u_tgt
-    dsq = (err ** 2).flatten(1).mean(1)
-    w = (1.0 / (dsq + c) ** (1.0 - gamma)).detach()
-    loss = (w * dsq).mean()
+    loss, u, dudt = mf_core(u_fn, z, t, r, target, gamma, c)
     return loss.detach(), _grads(loss, params), dict(u=u.detach(), dudt=dudt.detach())
 
 
@@ -472,10 +504,33 @@ def adamw_step(p, g, m, v, step, lr, wd, b1=0.9, b2=0.999, eps=1e-8):
 # --------------------------------------------------------------------------
 
 
+def heun_integrate(f, x, n_steps):
+    """The integrator of evaluators/sampling.py:50-96 == references/archive/flow.py:115-124: ``n_steps`` Heun steps
+    over ts = linspace(1, 0, n_steps) with dt = 1/n_steps; ``f(x, t_scalar) -> k``."""
+    dt = 1.0 / float(n_steps)
+    for t in torch.linspace(1.0, 0.0, n_steps, dtype=x.dtype):
+        k1 = f(x, t)
+        k2 = f(x - dt * k1, t - dt)
+        x = x - (dt / 2.0) * (k1 + k2)
+    return x
+
+
+def heun_two_time(f, x, n_steps):
+    """The two-time sampler of references/archive/imflow.py:170-182 (== mflow.py:154-166): t_vals = linspace(1, 0,
+    n_steps + 1); per step k1 = f(x, t, r), k2 = f(x - dt k1, r, r), x -= dt/2 (k1 + k2).  (The JAX sampler has no
+    counterpart: it always passes h = 0.)"""
+    tv = torch.linspace(1.0, 0.0, n_steps + 1, dtype=x.dtype)
+    for i in range(n_steps):
+        t, r = tv[i], tv[i + 1]
+        dt = t - r
+        k1 = f(x, t, r)
+        k2 = f(x - dt * k1, r, r)
+        x = x - (dt / 2.0) * (k1 + k2)
+    return x
+
+
 def heun_sample(apply, params, x, latents, n_steps, guidance_scale=1.0):
     """sample(), evaluators/sampling.py:50-96, from a given initial noise x."""
-    dt = 1.0 / float(n_steps)
-    ts = torch.linspace(1.0, 0.0, n_steps, dtype=x.dtype)
     B = x.shape[0]
 
     def f(xx, tval):
@@ -485,11 +540,7 @@ def heun_sample(apply, params, x, latents, n_steps, guidance_scale=1.0):
             k = guidance_scale * k + (1.0 - guidance_scale) * apply(params, xx, tp, None)
         return k
 
-    for t in ts:
-        k1 = f(x, t)
-        k2 = f(x - dt * k1, t - dt)
-        x = x - (dt / 2.0) * (k1 + k2)
-    return x
+    return heun_integrate(f, x, n_steps)
 
 
 def one_step_decode(apply, params, eps, latents):
@@ -498,3 +549,75 @@ def one_step_decode(apply, params, eps, latents):
     B = eps.shape[0]
     tp = torch.ones(B, 2, dtype=eps.dtype)
     return eps - apply(params, eps, tp, latents)
+
+
+# --------------------------------------------------------------------------
+# The archive variant: the net of references/archive/{flow,mflow,imflow}.py restated, so that the cores above can be
+# compared with numbers those files produced (tests/golden/gen_archive_flow_golden.py).  It differs from the JAX
+# MLP flow on purpose: SiLU, LayerNorm eps 1e-5 (torch default), class embedding instead of encoder
+# latents, emb(t) + emb(r) with 2 pi logspace(0, 3) frequencies in [sin, cos] order.
+# --------------------------------------------------------------------------
+
+
+def archive_embedding(x, dim):
+    """references/archive/imflow.py:79-83.  ``x``: [B].  (The frequencies are built from a float32 scalar there,
+    ``torch.log10(torch.tensor(1_000.))``; reproduced literally.)"""
+    freqs = torch.logspace(0, torch.log10(torch.tensor(1_000., dtype=torch.float32)), dim // 2, dtype=x.dtype)
+    ang = 2 * torch.pi * freqs[:, None] * x[None, :]
+    return torch.cat((ang.sin(), ang.cos()), 0).T
+
+
+def _lin(p, pre, x):
+    return x @ p[f"{pre}.weight"].T + p[f"{pre}.bias"]          # torch.nn.Linear: weight [out, in]
+
+
+def archive_net(p, x, t, r, cls_idx):
+    """ConditionalFlow.forward of references/archive/imflow.py:107-123 (``r=None``: flow.py:101-105, one time).
+    ``p``: the module's state_dict as {name: tensor}; ``t``, ``r``: [B, 1]."""
+    emb = p["cls_emb.0.weight"][cls_idx]
+    cls = _lin(p, "cls_emb.2", F.silu(emb))
+    cond = cls + archive_embedding(t[:, 0], cls.shape[-1])
+    if r is not None:
+        cond = cond + archive_embedding(r[:, 0], cls.shape[-1])
+    nb = 1 + max(int(k.split(".")[1]) for k in p if k.startswith("blocks."))
+    for i in range(nb):
+        b = f"blocks.{i}"
+        h = F.layer_norm(x, [x.shape[-1]])                      # eps 1e-5, no affine (imflow.py:99)
+        mod = _lin(p, f"{b}.cond.2", F.silu(_lin(p, f"{b}.cond.0", cond)))
+        s1, sh, s2 = mod.chunk(3, dim=-1)
+        h = _lin(p, f"{b}.mlp.2", F.silu(_lin(p, f"{b}.mlp.0", (1 + s1) * h + sh))) * (1 + s2)
+        x = x + h / nb
+    return x
+
+
+def _archive_grads(loss, p):
+    names = list(p)
+    gs = torch.autograd.grad(loss, [p[n] for n in names], allow_unused=True)
+    return {n: (g if g is not None else torch.zeros_like(p[n])) for n, g in zip(names, gs)}
+
+
+def archive_imf_loss(p, x0, cls_idx, e, t, r):
+    """improved_mean_flow_loss of references/archive/imflow.py:125-168 with the draws passed in (t, r: [B, 1]):
+    z = (1-t) x + t e, v = u(z, t, t), ``imf_core`` with the r-tangent, plain MSE against e - x."""
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    z = linear_interpolate(x0, e, t, 0.0, 1.0)
+    v = archive_net(p, z, t, t, cls_idx)
+    u, dudt, V = imf_core(lambda z_, t_, r_: archive_net(p, z_, t_, r_, cls_idx), v, z, t, r, tangent="r")
+    loss = ((V - linear_target(x0, e, 1.0)) ** 2).mean()
+    return loss.detach(), _archive_grads(loss, p), dict(v=v.detach(), u=u.detach(), dudt=dudt)
+
+
+def archive_mf_loss(p, x0, cls_idx, e, t, r, gamma=0.5, c=1e-3):
+    """mean_flow_loss of references/archive/mflow.py:128-152 through ``mf_core``."""
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    z = linear_interpolate(x0, e, t, 0.0, 1.0)
+    loss, u, dudt = mf_core(lambda z_, t_, r_: archive_net(p, z_, t_, r_, cls_idx), z, t, r, e - x0, gamma, c)
+    return loss.detach(), _archive_grads(loss, p), dict(u=u.detach(), dudt=dudt.detach())
+
+
+def archive_fm_loss(p, x0, cls_idx, e, t, noise_min=0.001, noise_max=0.999):
+    """flow_matching_loss of references/archive/flow.py:107-113 through ``fm_core`` (plain MSE)."""
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    pred, target = fm_core(lambda z_, t_: archive_net(p, z_, t_, None, cls_idx), x0, e, t, noise_min, noise_max)
+    loss = ((pred - target) ** 2).mean()
+    return loss.detach(), _archive_grads(loss, p), dict(pred=pred.detach())
