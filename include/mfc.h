@@ -109,9 +109,11 @@ int mfc_resample_poly(const float* x, int64_t rows, int64_t T_in, int64_t ldx, i
  * A,B,C,R in `dtype`; bias fp32 (may be NULL); R may be NULL.
  * Used for every Dense forward, its tangent (row-stacked [x; xdot] so the
  * weight tile is read once), input-gradient and
- * weight-gradient products.  `splitk` > 1 splits K over workgroups and
- * accumulates through the fp32 workspace `ws` (>= M*N floats, zeroed by the
- * call); the epilogue then runs as a second kernel. */
+ * weight-gradient products.  `splitk` > 1 splits K over workgroups: slice z writes its partial
+ * product into slab z of the fp32 workspace `ws` (mfc_gemm_ws_elems floats; not initialised by
+ * the caller) and the epilogue, a second kernel, sums the slabs in slice order -- DETERMINISTIC
+ * (bitwise reproducible run to run; no atomics). */
+int64_t mfc_gemm_ws_elems(int flags, int64_t M, int64_t N, int64_t K, int splitk);
 int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
              const void* A, int64_t lda, const void* B, int64_t ldb,
              void* C, int64_t ldc,
@@ -161,17 +163,22 @@ typedef struct {
 } mfc_cnx_params;
 
 /* fp32 gradient accumulators (+=) for the small parameters above */
+/* DETERMINISM.  No kernel of this section uses atomics: every workgroup stores its partial sums into its own record of
+ * the caller's workspace `ws` (mfc_cnx_ws_elems(R, s) floats, contents irrelevant on entry, may be shared by all
+ * calls on one stream) and a follow-up kernel inside the same call adds the records in workgroup order.  Results are
+ * bitwise reproducible run to run for a given (R, s) and mfc_cnx_max_blocks setting. */
 typedef struct {
     float* conv_w; float* conv_b; float* exp_w; float* exp_b;
     float* grn_gamma; float* grn_beta; float* con_w; float* con_b; float* ls;
 } mfc_cnx_grads;
 
-/* pass 1: S1[r,ch] += sum_hw g1^2 ; S2[r,ch] += sum_hw g1*g1dot (if h1dot).
- * scale/shift (and their tangents) are fp32 [R,16]; S1/S2 fp32 [R,32] must be
- * zeroed by the caller. */
+int64_t mfc_cnx_ws_elems(int64_t R, int s);
+
+/* pass 1: S1[r,ch] = sum_hw g1^2 ; S2[r,ch] = sum_hw g1*g1dot (if h1dot).
+ * scale/shift (and their tangents) are fp32 [R,16]; S1/S2 fp32 [R,32] are overwritten. */
 int mfc_cnx_stats(int dtype, int64_t R, int s, const void* h1, const void* h1dot,
                   const float* scale, const float* shift, const float* scaledot, const float* shiftdot,
-                  const mfc_cnx_params* p, float* S1, float* S2, void* stream);
+                  const mfc_cnx_params* p, float* S1, float* S2, float* ws, void* stream);
 
 /* GRN scalars from the statistics (conv_flow.py:32-37 and Appendix C):
  * G = sqrt(S1); n = mean_ch G; q = G/(n+1e-6); qdot from S2 (NULL: skipped). */
@@ -184,10 +191,10 @@ int mfc_cnx_apply(int dtype, int64_t R, int s, const void* h1, const void* h1dot
                   const mfc_cnx_params* p, const float* q, const float* qdot,
                   void* o, void* odot, void* stream);
 
-/* backward pass 1: dq[r,ch] += sum_hw dy*g1   (dq zeroed by caller) */
+/* backward pass 1: dq[r,ch] = sum_hw dy*g1   (overwritten) */
 int mfc_cnx_bwd_stats(int dtype, int64_t R, int s, const void* h0, const float* scale, const float* shift,
                       const mfc_cnx_params* p, const float* q, const void* dout,
-                      float* dq, void* stream);
+                      float* dq, float* ws, void* stream);
 
 /* kG[r,ch] = (dL/dG)/G from dq (zero where G == 0); dgamma[ch] += sum_r dq */
 int mfc_grn_bwd_finalize(int64_t R, const float* G, const float* dq, float* kG, float* dgamma, void* stream);
@@ -196,13 +203,13 @@ int mfc_grn_bwd_finalize(int64_t R, const float* G, const float* dq, float* kG, 
  * gradients of exp_w, exp_b, con_w and ls. */
 int mfc_cnx_bwd_main(int dtype, int64_t R, int s, const void* h0, const float* scale, const float* shift,
                      const mfc_cnx_params* p, const float* q, const float* kG, const void* dout,
-                     void* dc1, const mfc_cnx_grads* g, void* stream);
+                     void* dc1, const mfc_cnx_grads* g, float* ws, void* stream);
 
 /* backward pass 3: dh0 = LN/FiLM-backward(conv3x3^T(dc1) + dout); gradients of conv_w, conv_b, con_b and
- * grn_beta (the last two are linear in sum_hw dout); dscale/dshift [R,16] fp32 (+=, zeroed by caller). */
+ * grn_beta (the last two are linear in sum_hw dout); dscale/dshift [R,16] fp32 (overwritten). */
 int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h1, const float* rho0, const float* scale,
                      const float* shift, const mfc_cnx_params* p, const void* dc1, const void* dout,
-                     void* dh0, const mfc_cnx_grads* g, float* dscale, float* dshift, void* stream);
+                     void* dh0, const mfc_cnx_grads* g, float* dscale, float* dshift, float* ws, void* stream);
 
 /* Tuning / test hook: the persistent ConvNeXt kernels launch at most this many workgroups (default 2048, env
  * MFC_CNX_MAX_BLOCKS), each walking a contiguous range of tiles.  n > 0 sets it; returns the previous value. */
@@ -267,11 +274,13 @@ int mfc_gelu_bwd(int dtype, int64_t n, const void* pre, const void* dout, void* 
  *  adaptive weight on the per-example MEAN square, exponent p = 1-gamma.
  * Means are over Bglobal (data-parallel shards pass their local B rows).
  * Outputs: pe[B], seed[B] (dL/ddelta = seed*delta), loss (scalar, this shard's
- * contribution), du [B,D] dtype (NULL: skipped). */
+ * contribution), du [B,D] dtype (NULL: skipped).  ws: fp32 [B * MFC_FLOW_LOSS_WS_PER_ROW] partial sums (not
+ * initialised by the caller); the per-example sums and the batch mean are added in a fixed order (deterministic). */
+#define MFC_FLOW_LOSS_WS_PER_ROW 256
 int mfc_flow_loss(int dtype, int kind, int mode, int64_t B, int64_t Bglobal, int64_t D, const void* u,
                   const void* dudt, int64_t n_tan, const float* t, const float* r,
                   const float* target, float p, float c, float* pe, float* seed, float* loss,
-                  void* du, void* stream);
+                  void* du, float* ws, void* stream);
 
 /* out[N] (fp32) = (accumulate ? out : 0) + scale * sum_rows X[M,N]  -- bias gradients */
 int mfc_colsum(int dtype, int64_t M, int64_t N, const void* X, int64_t ld, float scale, float* out,

@@ -48,15 +48,17 @@ SIGNATURES = {
     "mfc_ln16_fwd": (c_int, [c_int, c_int64, _P, _P, _P, _P]),
     "mfc_ln16_jvp": (c_int, [c_int, c_int64, _P, _P, _P, _P, _P]),
     "mfc_cnx_max_blocks": (c_int64, [c_int64]),
+    "mfc_gemm_ws_elems": (c_int64, [c_int, c_int64, c_int64, c_int64, c_int]),
     "mfc_gemm_adamw": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, c_float, _P, _P, _P, _P,
                                c_float, c_float, c_float, c_float, c_float, c_int64, _P]),
-    "mfc_cnx_stats": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_cnx_stats": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_grn_finalize": (c_int, [c_int64, _P, _P, _P, _P, _P, _P]),
     "mfc_cnx_apply": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "mfc_cnx_bwd_stats": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_cnx_bwd_stats": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_cnx_ws_elems": (c_int64, [c_int64, c_int]),
     "mfc_grn_bwd_finalize": (c_int, [c_int64, _P, _P, _P, _P, _P]),
-    "mfc_cnx_bwd_main": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "mfc_cnx_bwd_conv": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_cnx_bwd_main": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_cnx_bwd_conv": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_adaln_fwd": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, _P]),
     "mfc_adaln_bwd": (c_int, [c_int, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int64, _P, c_int64, _P, _P, _P,
                               c_int64, _P]),
@@ -75,7 +77,7 @@ SIGNATURES = {
     "mfc_gelu_fwd": (c_int, [c_int, c_int64, c_int64, c_int64, _P, _P, _P]),
     "mfc_gelu_bwd": (c_int, [c_int, c_int64, _P, _P, _P, _P]),
     "mfc_flow_loss": (c_int, [c_int, c_int, c_int, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, _P,
-                              c_float, c_float, _P, _P, _P, _P, _P]),
+                              c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "mfc_colsum": (c_int, [c_int, c_int64, c_int64, _P, c_int64, c_float, _P, c_int, _P]),
     "mfc_axpby": (c_int, [c_int, c_int64, c_float, _P, c_float, _P, _P, _P]),
     "mfc_cast": (c_int, [c_int, c_int, c_int64, _P, _P, _P]),

@@ -28,9 +28,13 @@
 // apply pass), forward and backward.
 //
 // Workgroups are persistent over a contiguous range of tiles so weight-gradient
-// and per-row statistics accumulate in registers; they are reduced across the
-// workgroup's waves in LDS and flushed with one global atomic per element and
-// workgroup (hot-address fp32 atomics cost ~1 us per thousand).
+// and per-row statistics accumulate in registers.  Every reduction is FIXED-ORDER
+// (bitwise reproducible run to run, no atomics): the four waves of a workgroup add
+// their partial sums into an LDS scratch one after the other (wave 0, 1, 2, 3), the
+// workgroup stores the result into ITS OWN record of the caller's workspace with plain
+// stores, and a small follow-up kernel sums the records in workgroup order
+// (cnx_reduce_rows_kernel for per-row quantities, cnx_reduce_blocks_kernel for the
+// parameter gradients).  (Hot-address fp32 atomics also cost ~1 us per thousand.)
 #include "mfc_common.h"
 #include <cstdlib>
 
@@ -171,6 +175,7 @@ __device__ inline void ln_bwd_a(const float dn[4], const float n[4], float rho, 
 
 struct Geo {
     int64_t R; int s; int tilesX, tilesY; int64_t tilesPerImg, total, chunk;
+    int kmax;   // most rows r a workgroup's contiguous tile range can touch = records per workgroup
 };
 inline Geo make_geo(int64_t R, int s, int64_t maxBlocks, int64_t& grid) {
     Geo g;
@@ -181,7 +186,19 @@ inline Geo make_geo(int64_t R, int s, int64_t maxBlocks, int64_t& grid) {
     grid = g.total < maxBlocks ? g.total : maxBlocks;
     g.chunk = (g.total + grid - 1) / grid;
     grid = (g.total + g.chunk - 1) / g.chunk;
+    g.kmax = (int)((g.chunk + g.tilesPerImg - 2) / g.tilesPerImg) + 1;
     return g;
+}
+
+// Workspace records (floats).  Per (workgroup, k-th row of its range): REC_STATS forward statistics [S1 32 | S2 32],
+// REC_DQ backward statistic [dq 32], REC_CONV [conv_w 2304 | dscale 16 | dshift 16].  Per workgroup: REC_MAIN
+// [con_w 512 | exp_w 512 | ls 16 | exp_b 32], REC_TAIL [con_b 16 | conv_b 16 | grn_beta 32].
+constexpr int REC_STATS = 64, REC_DQ = 32, REC_CONV = 9 * 256 + 32, REC_MAIN = 1024 + 48, REC_TAIL = 64;
+inline int64_t ws_elems_for(int64_t R, int s, int64_t maxBlocks) {
+    int64_t grid;
+    const Geo g = make_geo(R, s, maxBlocks, grid);
+    const int64_t a = grid * g.kmax * REC_CONV + grid * REC_TAIL, b = grid * REC_MAIN, c = grid * g.kmax * REC_STATS;
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 constexpr int WS_TILES = 6;   // y0, y1, dp1, n1, de0, de1: what the weight-gradient transposes of one tile row hold
@@ -560,6 +577,7 @@ struct FwdArgs {
     float* S1; float* S2;          // stats mode
     const float* q; const float* qd;  // apply mode
     void* o; void* od;
+    float* ws;   // stats mode: per-(workgroup, row) records of REC_STATS floats
     int dbg;   // profiling ablations (env MFC_CNX_DBG): 1 = skip the row chain, 2 = request only the first tile
 };
 
@@ -607,20 +625,30 @@ cnx_fwd_kernel(FwdArgs a) {
     float qv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, qdv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     __amdgpu_buffer_rsrc_t rs_o = make_rsrc(nullptr, 0), rs_od = make_rsrc(nullptr, 0);
 
-    auto flush_stats = [&](int64_t r) {
+    int krow = 0;            // rows flushed so far = index of the next record of this workgroup
+    float* red = l.rho;      // [NWAVES][REC_STATS] cross-wave scratch (the 1/sigma tile region is unused by this kernel)
+    auto flush_stats = [&](int64_t) {
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float v1 = red_m(s1[j][i]);
-                    if (m == 0) atomicAdd(a.S1 + r * 32 + 16 * j + 4 * q + i, v1);
+                    if (m == 0) red[wave * REC_STATS + 16 * j + 4 * q + i] = v1;
                     if constexpr (JVP) {
                         const float v2 = red_m(s2[j][i]);
-                        if (m == 0) atomicAdd(a.S2 + r * 32 + 16 * j + 4 * q + i, v2);
+                        if (m == 0) red[wave * REC_STATS + 32 + 16 * j + 4 * q + i] = v2;
                     }
                     s1[j][i] = 0.f; s2[j][i] = 0.f;
                 }
+            __syncthreads();
+            if (threadIdx.x < (JVP ? 64 : 32)) {     // fixed order: wave 0 + wave 1 + wave 2 + wave 3
+                const int c = threadIdx.x;
+                const float v = ((red[c] + red[REC_STATS + c]) + red[2 * REC_STATS + c]) + red[3 * REC_STATS + c];
+                a.ws[((int64_t)blockIdx.x * a.geo.kmax + krow) * REC_STATS + c] = v;
+            }
+            ++krow;
+            __syncthreads();
         }
     };
 
@@ -743,6 +771,7 @@ struct BwdArgs {
     const float* q; const float* kG;
     const void* dout; const void* dc1_in;
     float* dq; void* dc1; void* dh0; float* dsc; float* dsh;
+    float* ws;   // partial-sum records (see REC_*)
     int dbg;
 };
 
@@ -806,16 +835,26 @@ cnx_bwd_kernel(BwdArgs a) {
     float dbe[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     __amdgpu_buffer_rsrc_t rs_dc = make_rsrc(nullptr, 0);
 
-    auto flush_row = [&](int64_t r) {
+    int krow = 0;
+    float* red = l.rho;      // [NWAVES][REC_DQ] cross-wave scratch
+    auto flush_row = [&](int64_t) {
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float v = red_m(dqp[j][i]);
-                    if (m == 0) atomicAdd(a.dq + r * 32 + 16 * j + 4 * q + i, v);
+                    if (m == 0) red[wave * REC_DQ + 16 * j + 4 * q + i] = v;
                     dqp[j][i] = 0.f;
                 }
+            __syncthreads();
+            if (threadIdx.x < REC_DQ) {
+                const int c = threadIdx.x;
+                const float v = ((red[c] + red[REC_DQ + c]) + red[2 * REC_DQ + c]) + red[3 * REC_DQ + c];
+                a.ws[((int64_t)blockIdx.x * a.geo.kmax + krow) * REC_DQ + c] = v;
+            }
+            ++krow;
+            __syncthreads();
         }
     };
 
@@ -968,37 +1007,41 @@ cnx_bwd_kernel(BwdArgs a) {
     }
     if (rcur >= 0) flush_row(rcur);
     if constexpr (MODE == 1) {
-        // the four waves' partial sums meet in LDS (ds_add_f32), then one global atomic per element and workgroup
+        // the four waves add their partial sums into the LDS scratch one after the other (fixed order), then the
+        // workgroup stores its record; cnx_reduce_blocks_kernel sums the records in workgroup order
         float* scratch = (float*)const_cast<T*>(l.tile(0, 0));   // con_w [32][16] | exp_w [16][32] | ls [16] | exp_b [32]
-        __syncthreads();                                          // every wave is past its last tile read
-        for (int i = threadIdx.x; i < 1024 + 48; i += NT) scratch[i] = 0.f;
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(scratch + (16 * j + 4 * q + e) * 16 + m, aWp[j][e]);
-                atomicAdd(scratch + 512 + (4 * q + e) * 32 + 16 * j + m, aWe[j][e]);
-            }
+        float vls[4], vbe[2][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float v1 = red_m(dls[i]);
-            if (m == 0) atomicAdd(scratch + 1024 + 4 * q + i, v1);
+            vls[i] = red_m(dls[i]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float v = red_m(dbe[j][i]);
-                if (m == 0) atomicAdd(scratch + 1040 + 16 * j + 4 * q + i, v);
-            }
+            for (int j = 0; j < 2; ++j) vbe[j][i] = red_m(dbe[j][i]);
         }
+        __syncthreads();                                          // every wave is past its last tile read
+        for (int i = threadIdx.x; i < REC_MAIN; i += NT) scratch[i] = 0.f;
         __syncthreads();
-        if (!(a.dbg & 1)) {
-            for (int i = threadIdx.x; i < 512; i += NT) {
-                atomicAdd(a.g.con_w + i, scratch[i]);
-                atomicAdd(a.g.exp_w + i, scratch[512 + i]);
+        for (int wv = 0; wv < NWAVES; ++wv) {
+            if (wave == wv) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        scratch[(16 * j + 4 * q + e) * 16 + m] += aWp[j][e];
+                        scratch[512 + (4 * q + e) * 32 + 16 * j + m] += aWe[j][e];
+                    }
+                if (m == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        scratch[1024 + 4 * q + i] += vls[i];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) scratch[1040 + 16 * j + 4 * q + i] += vbe[j][i];
+                    }
+                }
             }
-            if (threadIdx.x < 16) atomicAdd(a.g.ls + threadIdx.x, scratch[1024 + threadIdx.x]);
-            else if (threadIdx.x < 48) atomicAdd(a.g.exp_b + threadIdx.x - 16, scratch[1024 + threadIdx.x]);
+            __syncthreads();
         }
+        float* rec = a.ws + (int64_t)blockIdx.x * REC_MAIN;
+        for (int i = threadIdx.x; i < REC_MAIN; i += NT) rec[i] = (a.dbg & 1) ? 0.f : scratch[i];
     }
 }
 
@@ -1062,35 +1105,40 @@ cnx_bwd_conv_kernel(BwdArgs a) {
     { const float one = m < 9 ? 1.0f : 0.0f; make_frag(mk_int, one, one, one, one); }
     __amdgpu_buffer_rsrc_t rs_dh = make_rsrc(nullptr, 0);
 
-    // Gradient flushes: the four waves' partial sums meet in LDS first (ds_add_f32), then ONE global atomic per
-    // element and workgroup -- global fp32 atomics on a few hot addresses cost ~1 us per thousand.  `scratch` is
-    // a DMA buffer nothing is using at that point (see the call sites).
-    auto flush_row = [&](int64_t r, float* scratch) {
+    // Gradient flushes: the four waves add their partial sums into the LDS scratch one after the other (fixed order),
+    // then the workgroup stores record k of its range (conv_w | dscale | dshift of row r); the follow-up kernels sum
+    // the records in workgroup order.  `scratch` is a DMA buffer nothing is using at that point (see the call sites).
+    int krow = 0;
+    auto flush_row = [&](int64_t, float* scratch) {
         constexpr int NW = 9 * 256;
+        float v1[4], v2[4], bt[9];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v1[i] = red_m(dscp[i]); v2[i] = red_m(dshp[i]); dscp[i] = 0.f; dshp[i] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) bt[t] = __shfl(aB[t & 3], (t >> 2) * 16 + m);   // B[tap t][oc = m]
         __syncthreads();
         for (int i = threadIdx.x; i < NW + 32; i += NT) scratch[i] = 0.f;
         __syncthreads();
+        for (int wv = 0; wv < NWAVES; ++wv) {
+            if (wave == wv) {
+                if (m == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float v1 = red_m(dscp[i]), v2 = red_m(dshp[i]);
-            if (m == 0) { atomicAdd(scratch + NW + 4 * q + i, v1); atomicAdd(scratch + NW + 16 + 4 * q + i, v2); }
-            dscp[i] = 0.f; dshp[i] = 0.f;
+                    for (int i = 0; i < 4; ++i) { scratch[NW + 4 * q + i] += v1[i]; scratch[NW + 16 + 4 * q + i] += v2[i]; }
+                }
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        scratch[(t * 16 + 4 * q + e) * 16 + m] += sc1[e] * aWc[t][e] + shr[e] * bt[t];
+            }
+            __syncthreads();
         }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const float bt = __shfl(aB[t & 3], (t >> 2) * 16 + m);   // B[tap t][oc = m]
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                atomicAdd(scratch + (t * 16 + 4 * q + e) * 16 + m, sc1[e] * aWc[t][e] + shr[e] * bt);
-            aWc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int t = 0; t < 9; ++t) aWc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         aB = f32x4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();
-        if (!(a.dbg & 1)) {
-            for (int i = threadIdx.x; i < NW; i += NT) atomicAdd(a.g.conv_w + i, scratch[i]);
-            if (threadIdx.x < 16) atomicAdd(a.dsc + r * 16 + threadIdx.x, scratch[NW + threadIdx.x]);
-            else if (threadIdx.x < 32) atomicAdd(a.dsh + r * 16 + threadIdx.x - 16, scratch[NW + threadIdx.x]);
-        }
+        float* rec = a.ws + ((int64_t)blockIdx.x * a.geo.kmax + krow) * REC_CONV;
+        for (int i = threadIdx.x; i < NW + 32; i += NT) rec[i] = (a.dbg & 1) ? 0.f : scratch[i];
+        ++krow;
         __syncthreads();
     };
 
@@ -1202,15 +1250,18 @@ cnx_bwd_conv_kernel(BwdArgs a) {
     }
     float* scratch = (float*)const_cast<T*>(l.tile(1, 0));   // (flush_row's first barrier: every wave is past its last dc1 read)
     if (rcur >= 0) flush_row(rcur, scratch);
+    // records this workgroup's range did not reach: zeros (the reduction walks every record)
+    for (int k = krow; k < a.geo.kmax; ++k) {
+        float* rec = a.ws + ((int64_t)blockIdx.x * a.geo.kmax + k) * REC_CONV;
+        for (int i = threadIdx.x; i < REC_CONV; i += NT) rec[i] = 0.f;
+    }
     // con_b (16), conv_b (16), grn_beta (32): d con_b = ls * sum dout, d conv_b = sum dc1,
     // d grn_beta[e] = sum_pixels dy[e] = sum_c Wp[e][c] (ls[c] sum_pixels dout[c])
-    if (threadIdx.x < 64) scratch[threadIdx.x] = 0.f;
-    __syncthreads();
+    float vb[4], vc[4], vbeta[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float v1 = red_m(dsum[i]), v2 = red_m(dcsum[i]);
-        dsum[i] = v1 * a.p.ls[4 * q + i];    // this wave's sum of dp1[c], c = 4q + i (on every lane)
-        if (m == 0) { atomicAdd(scratch + 4 * q + i, dsum[i]); atomicAdd(scratch + 16 + 4 * q + i, v2); }
+        vb[i] = red_m(dsum[i]) * a.p.ls[4 * q + i];    // this wave's sum of dp1[c], c = 4q + i (on every lane)
+        vc[i] = red_m(dcsum[i]);
     }
     {
         const T* pw = (const T*)a.p.con_w;   // [32][16]
@@ -1218,16 +1269,70 @@ cnx_bwd_conv_kernel(BwdArgs a) {
         for (int j = 0; j < 2; ++j) {
             float acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc += St<T>::ld(pw + (16 * j + m) * 16 + 4 * q + i) * dsum[i];
-            acc = red_q(acc);
-            if (q == 0) atomicAdd(scratch + 32 + 16 * j + m, acc);
+            for (int i = 0; i < 4; ++i) acc += St<T>::ld(pw + (16 * j + m) * 16 + 4 * q + i) * vb[i];
+            vbeta[j] = red_q(acc);
         }
     }
     __syncthreads();
-    if (!(a.dbg & 1)) {
-        if (threadIdx.x < 16) atomicAdd(a.g.con_b + threadIdx.x, scratch[threadIdx.x]);
-        else if (threadIdx.x < 32) atomicAdd(a.g.conv_b + threadIdx.x - 16, scratch[threadIdx.x]);
-        else if (threadIdx.x < 64) atomicAdd(a.g.beta + threadIdx.x - 32, scratch[threadIdx.x]);
+    if (threadIdx.x < REC_TAIL) scratch[threadIdx.x] = 0.f;
+    __syncthreads();
+    for (int wv = 0; wv < NWAVES; ++wv) {
+        if (wave == wv) {
+            if (m == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { scratch[4 * q + i] += vb[i]; scratch[16 + 4 * q + i] += vc[i]; }
+            }
+            if (q == 0) { scratch[32 + m] += vbeta[0]; scratch[48 + m] += vbeta[1]; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < REC_TAIL)
+        a.ws[(int64_t)gridDim.x * a.geo.kmax * REC_CONV + (int64_t)blockIdx.x * REC_TAIL + threadIdx.x] =
+            (a.dbg & 1) ? 0.f : scratch[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------
+// fixed-order reductions of the workspace records
+// ---------------------------------------------------------------------------
+// Per-row quantities: out0[r][c] (c < n0) / out1[r][c - n0] (c >= n0) = sum over the workgroups b whose tile range
+// touches row r, in ascending b, of record (b, r - first_row(b)) at [off + c].
+__global__ void __launch_bounds__(256)
+cnx_reduce_rows_kernel(const float* ws, Geo g, int rec, int off, int n, int n0, float* out0, float* out1) {
+    const int64_t idx = blockIdx.x * 256LL + threadIdx.x;
+    if (idx >= g.R * n) return;
+    const int64_t r = idx / n;
+    const int c = (int)(idx - r * n);
+    const int64_t b0 = (r * g.tilesPerImg) / g.chunk, b1 = ((r + 1) * g.tilesPerImg - 1) / g.chunk;
+    float v = 0.f;
+    for (int64_t b = b0; b <= b1; ++b) {
+        const int64_t k = r - (b * g.chunk) / g.tilesPerImg;
+        v += ws[(b * g.kmax + k) * rec + off + c];
+    }
+    if (c < n0) out0[r * n0 + c] = v;
+    else out1[r * (n - n0) + c - n0] = v;
+}
+
+// Parameter gradients: dst[i] += sum over all `nrec` records, ascending, of rec[off + i].  Tree with a fixed shape: 16
+// waves each sum the records congruent to their index mod 16 (64 consecutive elements per wave instruction), then the
+// 16 partial sums are added in wave order.
+struct RedSeg { float* dst; int begin, end; };     // record elements [begin, end) -> dst[0 .. end - begin)
+struct RedSegs { RedSeg s[4]; int n; };
+__global__ void __launch_bounds__(1024)
+cnx_reduce_blocks_kernel(const float* ws, int64_t nrec, int rec, int total, RedSegs segs) {
+    __shared__ float part[16][64];
+    const int il = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
+    float v = 0.f;
+    if (i < total)
+        for (int64_t b = w; b < nrec; b += 16) v += ws[b * rec + i];
+    part[w][il] = v;
+    __syncthreads();
+    if (w == 0 && i < total) {
+        float sum = part[0][il];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) sum += part[k][il];
+        for (int k = 0; k < segs.n; ++k)
+            if (i >= segs.s[k].begin && i < segs.s[k].end) segs.s[k].dst[i - segs.s[k].begin] += sum;
     }
 }
 
@@ -1305,7 +1410,14 @@ __global__ void grn_bwd_finalize_kernel(int64_t R, const float* G, const float* 
     const float inv = 1.0f / (n + GRN_EPS);
     const float dG = d * inv - sdg * inv * inv * (1.0f / 32.0f);
     kG[r * 32 + c] = g > 0.f ? dG / g : 0.f;
-    atomicAdd(dgamma + c, d);
+}
+// dgamma[c] += sum_r dq[r][c], rows in ascending order (fixed order; R is a batch size)
+__global__ void grn_dgamma_kernel(int64_t R, const float* dq, float* dgamma) {
+    const int c = threadIdx.x;
+    if (c >= 32) return;
+    float v = 0.f;
+    for (int64_t r = 0; r < R; ++r) v += dq[r * 32 + c];
+    dgamma[c] += v;
 }
 
 inline Dev to_dev(const mfc_cnx_params* p) {
@@ -1330,6 +1442,18 @@ inline int launch_k(K kern, int64_t grid, size_t lds, hipStream_t st, const A& a
     return mfc_launch_status();
 }
 
+inline int reduce_rows(const float* ws, const Geo& g, int rec, int off, int n, int n0, float* out0, float* out1,
+                       hipStream_t st) {
+    const int64_t blocks = ceil_div64(g.R * n, 256);
+    hipLaunchKernelGGL(cnx_reduce_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ws, g, rec, off, n, n0, out0, out1);
+    return mfc_launch_status();
+}
+inline int reduce_blocks(const float* ws, int64_t nrec, int rec, int total, const RedSegs& segs, hipStream_t st) {
+    hipLaunchKernelGGL(cnx_reduce_blocks_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, st, ws, nrec, rec,
+                       total, segs);
+    return mfc_launch_status();
+}
+
 template <typename T>
 int fwd_launch(bool jvp, int mode, const FwdArgs& a, int64_t grid, hipStream_t st) {
     const size_t lds = lds2_bytes<T>(jvp ? 2 : 1, false);
@@ -1344,24 +1468,26 @@ int fwd_launch(bool jvp, int mode, const FwdArgs& a, int64_t grid, hipStream_t s
 int fwd_common(int dtype, int mode, int64_t R, int s, const void* h0, const void* h0dot,
                const float* scale, const float* shift, const float* scaledot, const float* shiftdot,
                const mfc_cnx_params* p, float* S1, float* S2, const float* q, const float* qdot,
-               void* o, void* odot, void* stream) {
+               void* o, void* odot, float* ws, void* stream) {
     if (!h0 || !scale || !shift || !params_ok(p)) return MFC_EFAULT;
     if (R <= 0 || s <= 0) return MFC_EINVAL;
     if (s > MAX_S) return MFC_ENOSYS;
     if (dtype != MFC_F32 && dtype != MFC_BF16) return MFC_EINVAL;
     const bool jvp = h0dot != nullptr;
     if (jvp && (!scaledot || !shiftdot)) return MFC_EFAULT;
-    if (mode == 0 && (!S1 || (jvp && !S2))) return MFC_EFAULT;
+    if (mode == 0 && (!S1 || (jvp && !S2) || !ws)) return MFC_EFAULT;
     if (mode == 1 && (!q || !o || (jvp && (!qdot || !odot)))) return MFC_EFAULT;
     FwdArgs a;
     int64_t grid;
     a.geo = make_geo(R, s, MAX_BLOCKS, grid);
     a.h0 = h0; a.h0d = h0dot; a.sc = scale; a.sh = shift; a.scd = scaledot; a.shd = shiftdot;
-    a.p = to_dev(p); a.S1 = S1; a.S2 = S2; a.q = q; a.qd = qdot; a.o = o; a.od = odot;
+    a.p = to_dev(p); a.S1 = S1; a.S2 = S2; a.q = q; a.qd = qdot; a.o = o; a.od = odot; a.ws = ws;
     static const int dbg = getenv("MFC_CNX_DBG") ? atoi(getenv("MFC_CNX_DBG")) : 0;
     a.dbg = dbg;
     hipStream_t st = (hipStream_t)stream;
-    return dtype == MFC_F32 ? fwd_launch<float>(jvp, mode, a, grid, st) : fwd_launch<u16>(jvp, mode, a, grid, st);
+    int rc = dtype == MFC_F32 ? fwd_launch<float>(jvp, mode, a, grid, st) : fwd_launch<u16>(jvp, mode, a, grid, st);
+    if (!rc && mode == 0) rc = reduce_rows(ws, a.geo, REC_STATS, 0, jvp ? 64 : 32, 32, S1, S2, st);
+    return rc;
 }
 
 }  // namespace
@@ -1369,9 +1495,14 @@ int fwd_common(int dtype, int mode, int64_t R, int s, const void* h0, const void
 extern "C" int mfc_cnx_stats(int dtype, int64_t R, int s, const void* h1, const void* h1dot,
                              const float* scale, const float* shift, const float* scaledot,
                              const float* shiftdot, const mfc_cnx_params* p, float* S1, float* S2,
-                             void* stream) {
+                             float* ws, void* stream) {
     return fwd_common(dtype, 0, R, s, h1, h1dot, scale, shift, scaledot, shiftdot, p, S1, S2, nullptr, nullptr,
-                      nullptr, nullptr, stream);
+                      nullptr, nullptr, ws, stream);
+}
+
+extern "C" int64_t mfc_cnx_ws_elems(int64_t R, int s) {
+    if (R <= 0 || s <= 0 || s > MAX_S) return -1;
+    return ws_elems_for(R, s, MAX_BLOCKS);
 }
 
 extern "C" int mfc_cnx_apply(int dtype, int64_t R, int s, const void* h1, const void* h1dot,
@@ -1379,7 +1510,7 @@ extern "C" int mfc_cnx_apply(int dtype, int64_t R, int s, const void* h1, const 
                              const float* shiftdot, const mfc_cnx_params* p, const float* q, const float* qdot,
                              void* o, void* odot, void* stream) {
     return fwd_common(dtype, 1, R, s, h1, h1dot, scale, shift, scaledot, shiftdot, p, nullptr, nullptr, q, qdot,
-                      o, odot, stream);
+                      o, odot, nullptr, stream);
 }
 
 extern "C" int mfc_grn_finalize(int64_t R, const float* S1, const float* S2, float* G, float* q, float* qdot,
@@ -1399,6 +1530,7 @@ extern "C" int mfc_grn_bwd_finalize(int64_t R, const float* G, const float* dq, 
     const int64_t blocks = ceil_div64(R * 32, 256);
     hipLaunchKernelGGL(grn_bwd_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, R, G,
                        dq, kG, dgamma);
+    hipLaunchKernelGGL(grn_dgamma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, R, dq, dgamma);
     return mfc_launch_status();
 }
 
@@ -1406,24 +1538,26 @@ static const int BWD_DBG = getenv("MFC_CNX_BWD_DBG") ? atoi(getenv("MFC_CNX_BWD_
 
 extern "C" int mfc_cnx_bwd_stats(int dtype, int64_t R, int s, const void* h0, const float* scale,
                                  const float* shift, const mfc_cnx_params* p, const float* q, const void* dout,
-                                 float* dq, void* stream) {
-    if (!h0 || !scale || !shift || !params_ok(p) || !q || !dout || !dq) return MFC_EFAULT;
+                                 float* dq, float* ws, void* stream) {
+    if (!h0 || !scale || !shift || !params_ok(p) || !q || !dout || !dq || !ws) return MFC_EFAULT;
     if (R <= 0 || s <= 0 || (dtype != MFC_F32 && dtype != MFC_BF16)) return MFC_EINVAL;
     if (s > MAX_S) return MFC_ENOSYS;
     BwdArgs a = {};
     int64_t grid;
     a.geo = make_geo(R, s, MAX_BLOCKS, grid);
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(nullptr);
-    a.q = q; a.dout = dout; a.dq = dq; a.dbg = BWD_DBG;
+    a.q = q; a.dout = dout; a.dq = dq; a.ws = ws; a.dbg = BWD_DBG;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFC_F32) return launch_k(cnx_bwd_kernel<float, 0>, grid, lds2_bytes<float>(1, false), st, a);
-    return launch_k(cnx_bwd_kernel<u16, 0>, grid, lds2_bytes<u16>(1, false), st, a);
+    int rc = dtype == MFC_F32 ? launch_k(cnx_bwd_kernel<float, 0>, grid, lds2_bytes<float>(1, false), st, a)
+                              : launch_k(cnx_bwd_kernel<u16, 0>, grid, lds2_bytes<u16>(1, false), st, a);
+    if (!rc) rc = reduce_rows(ws, a.geo, REC_DQ, 0, 32, 32, dq, nullptr, st);
+    return rc;
 }
 
 extern "C" int mfc_cnx_bwd_main(int dtype, int64_t R, int s, const void* h0, const float* scale,
                                 const float* shift, const mfc_cnx_params* p, const float* q, const float* kG,
-                                const void* dout, void* dc1, const mfc_cnx_grads* g, void* stream) {
-    if (!h0 || !scale || !shift || !params_ok(p) || !q || !kG || !dout || !dc1 || !g) return MFC_EFAULT;
+                                const void* dout, void* dc1, const mfc_cnx_grads* g, float* ws, void* stream) {
+    if (!h0 || !scale || !shift || !params_ok(p) || !q || !kG || !dout || !dc1 || !g || !ws) return MFC_EFAULT;
     if (!g->con_w || !g->ls || !g->exp_w || !g->exp_b) return MFC_EFAULT;
     if (R <= 0 || s <= 0 || (dtype != MFC_F32 && dtype != MFC_BF16)) return MFC_EINVAL;
     if (s > MAX_S) return MFC_ENOSYS;
@@ -1431,18 +1565,23 @@ extern "C" int mfc_cnx_bwd_main(int dtype, int64_t R, int s, const void* h0, con
     int64_t grid;
     a.geo = make_geo(R, s, MAX_BLOCKS, grid);
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(g);
-    a.q = q; a.kG = kG; a.dout = dout; a.dc1 = dc1; a.dbg = BWD_DBG;
+    a.q = q; a.kG = kG; a.dout = dout; a.dc1 = dc1; a.ws = ws; a.dbg = BWD_DBG;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFC_F32) return launch_k(cnx_bwd_kernel<float, 1>, grid, lds2_bytes<float>(2, true), st, a);
-    return launch_k(cnx_bwd_kernel<u16, 1>, grid, lds2_bytes<u16>(2, true), st, a);
+    int rc = dtype == MFC_F32 ? launch_k(cnx_bwd_kernel<float, 1>, grid, lds2_bytes<float>(2, true), st, a)
+                              : launch_k(cnx_bwd_kernel<u16, 1>, grid, lds2_bytes<u16>(2, true), st, a);
+    if (!rc) {
+        RedSegs sg = {{{g->con_w, 0, 512}, {g->exp_w, 512, 1024}, {g->ls, 1024, 1040}, {g->exp_b, 1040, 1072}}, 4};
+        rc = reduce_blocks(ws, grid, REC_MAIN, REC_MAIN, sg, st);
+    }
+    return rc;
 }
 
 extern "C" int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, const float* rho0,
                                 const float* scale, const float* shift, const mfc_cnx_params* p, const void* dc1,
                                 const void* dout, void* dh0, const mfc_cnx_grads* g, float* dscale, float* dshift,
-                                void* stream) {
+                                float* ws, void* stream) {
     if (!h0 || !rho0 || !scale || !shift || !params_ok(p) || !dc1 || !dout || !dh0 || !g || !g->conv_w || !g->conv_b ||
-        !g->con_b || !g->grn_beta || !dscale || !dshift)
+        !g->con_b || !g->grn_beta || !dscale || !dshift || !ws)
         return MFC_EFAULT;
     if (R <= 0 || s <= 0 || (dtype != MFC_F32 && dtype != MFC_BF16)) return MFC_EINVAL;
     if (s > MAX_S) return MFC_ENOSYS;
@@ -1450,10 +1589,20 @@ extern "C" int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, con
     int64_t grid;
     a.geo = make_geo(R, s, MAX_BLOCKS, grid);
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(g);
-    a.rho = rho0; a.dc1_in = dc1; a.dout = dout; a.dh0 = dh0; a.dsc = dscale; a.dsh = dshift; a.dbg = BWD_DBG;
+    a.rho = rho0; a.dc1_in = dc1; a.dout = dout; a.dh0 = dh0; a.dsc = dscale; a.dsh = dshift; a.ws = ws; a.dbg = BWD_DBG;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFC_F32) return launch_k(cnx_bwd_conv_kernel<float>, grid, lds2_bytes<float>(3, false), st, a);
-    return launch_k(cnx_bwd_conv_kernel<u16>, grid, lds2_bytes<u16>(3, false), st, a);
+    int rc = dtype == MFC_F32 ? launch_k(cnx_bwd_conv_kernel<float>, grid, lds2_bytes<float>(3, false), st, a)
+                              : launch_k(cnx_bwd_conv_kernel<u16>, grid, lds2_bytes<u16>(3, false), st, a);
+    if (!rc) rc = reduce_rows(ws, a.geo, REC_CONV, 9 * 256, 32, 16, dscale, dshift, st);
+    if (!rc) {
+        RedSegs sg = {{{g->conv_w, 0, 9 * 256}, {nullptr, 0, 0}, {nullptr, 0, 0}, {nullptr, 0, 0}}, 1};
+        rc = reduce_blocks(ws, grid * a.geo.kmax, REC_CONV, 9 * 256, sg, st);
+    }
+    if (!rc) {
+        RedSegs sg = {{{g->con_b, 0, 16}, {g->conv_b, 16, 32}, {g->grn_beta, 32, 64}, {nullptr, 0, 0}}, 3};
+        rc = reduce_blocks(ws + grid * a.geo.kmax * REC_CONV, grid, REC_TAIL, REC_TAIL, sg, st);
+    }
+    return rc;
 }
 
 extern "C" int mfc_ln16_fwd(int dtype, int64_t n_pixels, const void* x, void* y, float* rstd, void* stream) {

@@ -165,10 +165,11 @@ __global__ void gelu_bwd_kernel(int64_t n, const T* pre, const T* dout, T* din) 
 // ---- loss ---------------------------------------------------------------------
 // kind 0 (iMF / FM): delta = u + coef*dudt - target, coef = (t - r)      loss_strategies.py:270
 // kind 1 (MF):       delta = u - (target - clip(t-r,0,1) dudt)           loss_strategies.py:184-188
-// pe[b] = sum_d delta^2
+// pe[b] = sum_d delta^2: workgroup (x, b) stores its partial sum in part[b * gridDim.x + x]; loss_finalize_kernel adds
+// the partials of an example in ascending x (fixed order, no atomics: the loss weight 1/(pe + c) feeds every gradient)
 template <typename T>
 __global__ void loss_pe_kernel(int kind, int64_t B, int64_t D, const T* u, const T* dudt, int64_t n_tan,
-                               const float* t, const float* r, const float* target, float* pe) {
+                               const float* t, const float* r, const float* target, float* part) {
     __shared__ float red[ET / 64];
     const int64_t b = blockIdx.y;
     float coef = 0.f;
@@ -188,7 +189,7 @@ __global__ void loss_pe_kernel(int kind, int64_t B, int64_t D, const T* u, const
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int i = 0; i < ET / 64; ++i) s += red[i];
-        atomicAdd(pe + b, s);
+        part[b * gridDim.x + blockIdx.x] = s;
     }
 }
 
@@ -197,12 +198,18 @@ __global__ void loss_pe_kernel(int kind, int64_t B, int64_t D, const T* u, const
 //  mode 1: plain MSE                           loss = sum pe / (Bg D),                  seed = 2 / (Bg D)
 //  mode 2: MeanFlow adaptive (loss_strategies.py:190-196) dsq = pe/D, w = 1/(dsq+c)^(1-gamma),
 //          loss = mean_b(w dsq), seed = 2 w / (Bg D)
-__global__ void loss_finalize_kernel(int mode, int64_t B, int64_t Bglobal, int64_t D, const float* pe, float p,
-                                     float c, float* seed, float* loss) {
+__global__ void loss_finalize_kernel(int mode, int64_t B, int64_t Bglobal, int64_t D, const float* part, int nparts,
+                                     float* pe, float p, float c, float* seed, float* loss) {
+    __shared__ float contrib[256];
     float acc = 0.f;
-    for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
-        const float v = pe[b];
-        float w, l;
+    for (int64_t b0 = 0; b0 < B; b0 += blockDim.x) {
+      const int64_t b = b0 + threadIdx.x;
+      float l = 0.f;
+      if (b < B) {
+        float v = 0.f;
+        for (int k = 0; k < nparts; ++k) v += part[b * nparts + k];
+        pe[b] = v;
+        float w;
         if (mode == 0) { w = 1.0f / powf(v + c, p); l = w * v / (float)Bglobal; seed[b] = 2.0f * w / (float)Bglobal; }
         else if (mode == 1) { l = v / ((float)Bglobal * (float)D); seed[b] = 2.0f / ((float)Bglobal * (float)D); }
         else {
@@ -211,17 +218,17 @@ __global__ void loss_finalize_kernel(int mode, int64_t B, int64_t Bglobal, int64
             l = w * dsq / (float)Bglobal;
             seed[b] = 2.0f * w / ((float)Bglobal * (float)D);
         }
-        acc += l;
+      }
+      // examples in ascending order (the reference's mean over the batch): one thread adds this round's contributions
+      contrib[threadIdx.x] = l;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+          const int n = (int)((B - b0) < (int64_t)blockDim.x ? (B - b0) : (int64_t)blockDim.x);
+          for (int i = 0; i < n; ++i) acc += contrib[i];
+      }
+      __syncthreads();
     }
-    __shared__ float red[16];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float s = 0.f;
-        for (int i = 0; i < (int)(blockDim.x / 64); ++i) s += red[i];
-        *loss = s;
-    }
+    if (threadIdx.x == 0) *loss = acc;
 }
 
 // du[b,d] = seed[b] * delta[b,d]
@@ -445,23 +452,23 @@ extern "C" int mfc_gelu_bwd(int dtype, int64_t n, const void* pre, const void* d
 extern "C" int mfc_flow_loss(int dtype, int kind, int mode, int64_t B, int64_t Bglobal, int64_t D, const void* u,
                              const void* dudt, int64_t n_tan, const float* t, const float* r,
                              const float* target, float p, float c, float* pe, float* seed, float* loss,
-                             void* du, void* stream) {
-    if (!u || !target || !pe || !seed || !loss) return MFC_EFAULT;
+                             void* du, float* ws, void* stream) {
+    if (!u || !target || !pe || !seed || !loss || !ws) return MFC_EFAULT;
     if (dudt && (!t || !r)) return MFC_EFAULT;
     if (B <= 0 || D <= 0 || Bglobal < B || n_tan < 0 || n_tan > B || !DT_OK(dtype)) return MFC_EINVAL;
     if (kind < 0 || kind > 1 || mode < 0 || mode > 2 || B > 65535) return MFC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(pe, 0, B * sizeof(float), st) != hipSuccess) return MFC_EHIP;
     int64_t gx = ceil_div64(D, ET * 8);
-    if (gx > 256) gx = 256;
+    if (gx > MFC_FLOW_LOSS_WS_PER_ROW) gx = MFC_FLOW_LOSS_WS_PER_ROW;
     dim3 g1((unsigned)gx, (unsigned)B);
     if (dtype == MFC_F32)
         hipLaunchKernelGGL(loss_pe_kernel<float>, g1, dim3(ET), 0, st, kind, B, D, (const float*)u,
-                           (const float*)dudt, n_tan, t, r, target, pe);
+                           (const float*)dudt, n_tan, t, r, target, ws);
     else
         hipLaunchKernelGGL(loss_pe_kernel<u16>, g1, dim3(ET), 0, st, kind, B, D, (const u16*)u, (const u16*)dudt,
-                           n_tan, t, r, target, pe);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, mode, B, Bglobal, D, pe, p, c, seed, loss);
+                           n_tan, t, r, target, ws);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, mode, B, Bglobal, D, (const float*)ws, (int)gx,
+                       pe, p, c, seed, loss);
     if (du) {
         if (dtype == MFC_F32)
             hipLaunchKernelGGL(loss_grad_kernel<float>, dim3(grid_for(B * D)), dim3(ET), 0, st, kind, B, D,

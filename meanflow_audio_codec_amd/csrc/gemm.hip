@@ -38,7 +38,8 @@ struct GemmArgs {
     const void* R; int64_t ldr; float beta;
     int accum;
     int64_t kchunk;  // K range per blockIdx.z
-    float* ws;       // split-K workspace (fp32 [M,N]) or null
+    float* ws;       // split-K workspace (fp32 [slices][M,N], one slab per K slice) or null
+    int64_t ws_slab; // elements per slab (M * N)
     int vecA, vecB;  // 16-byte vector loads legal
     int vecC;        // 16-byte row-contiguous C (and R) accesses legal
     int m_fast;      // blockIdx.x walks M tiles (else N tiles)
@@ -380,7 +381,9 @@ gemm_kernel(GemmArgs g) {
                 if (row >= g.M) continue;
                 float v = acc[i][j][e];
                 if (g.ws) {
-                    atomicAdd(g.ws + row * g.N + col, v);
+                    // split-K: slice z owns slab z of the workspace (plain stores; the epilogue sums the slabs in
+                    // slice order, so the result does not depend on the order workgroups finish in)
+                    g.ws[(int64_t)blockIdx.z * g.ws_slab + row * g.N + col] = v;
                 } else {
                     if (g.bias && row < g.bias_rows) v += g.bias[col];
                     v *= g.alpha;
@@ -665,13 +668,18 @@ ln16_tangent_kernel(int64_t rows, int64_t groups, T* C, int64_t ldc, int64_t bia
 // split-K / activation epilogue over the fp32 workspace
 template <typename T>
 __global__ void __launch_bounds__(256)
-gemm_epilogue_kernel(const float* ws, int64_t M, int64_t N, T* C, int64_t ldc,
+gemm_epilogue_kernel(const float* ws, int nslab, int64_t M, int64_t N, T* C, int64_t ldc,
                      const float* bias, int64_t bias_rows, int gelu, int64_t act_rows,
                      float alpha, const T* R, int64_t ldr, float beta, int accum) {
     const int64_t total = M * N;
+    auto slabsum = [&](int64_t o) {       // fixed order: slice 0, 1, 2, ...
+        float v = ws[o];
+        for (int z = 1; z < nslab; ++z) v += ws[(int64_t)z * total + o];
+        return v;
+    };
     for (int64_t o = blockIdx.x * 256LL + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
         const int64_t row = o / N, col = o - row * N;
-        float v = ws[o];
+        float v = slabsum(o);
         if (bias && row < bias_rows) v += bias[col];
         if (gelu) {
             if (row < act_rows) {
@@ -679,7 +687,7 @@ gemm_epilogue_kernel(const float* ws, int64_t M, int64_t N, T* C, int64_t ldc,
             } else {
                 // tangent row: t * gelu'(pre) with pre = primal pre-activation
                 const int64_t pr = row - act_rows;
-                float pre = ws[pr * N + col];
+                float pre = slabsum(pr * N + col);
                 if (bias && pr < bias_rows) pre += bias[col];
                 v = v * gelu_grad_f(pre);
             }
@@ -737,7 +745,7 @@ int launch(int flags, GemmArgs g, int bk, int splitk, int gelu, int64_t act_rows
         int64_t blocks = ceil_div64(g.M * g.N, 256);
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL((gemm_epilogue_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st,
-                           (const float*)g.ws, g.M, g.N, (T*)g.C, g.ldc, g.bias, g.bias_rows, gelu, act_rows,
+                           (const float*)g.ws, splitk, g.M, g.N, (T*)g.C, g.ldc, g.bias, g.bias_rows, gelu, act_rows,
                            g.alpha, (const T*)g.R, g.ldr, g.beta, g.accum);
         rc = mfc_launch_status();
     }
@@ -764,6 +772,22 @@ int gemm_impl(int dtype, int flags, int64_t M, int64_t N, int64_t K, const void*
               const void* R, int64_t ldr, float beta_res, int splitk, float* ws, float* ln_rstd, const OptArgs* opt,
               void* stream);
 }  // namespace
+
+namespace {
+// effective number of K slices for a requested split (the chunk is rounded up to whole K-steps of the LDS tiles)
+inline int effective_splitk(int64_t K, int splitk) {
+    if (splitk < 1) splitk = 1;
+    const int bk = K <= 32 ? 32 : 64;
+    const int64_t kc = ceil_div64(ceil_div64(K, splitk), bk) * bk;
+    return (int)ceil_div64(K, kc);
+}
+}  // namespace
+
+extern "C" int64_t mfc_gemm_ws_elems(int flags, int64_t M, int64_t N, int64_t K, int splitk) {
+    if (M <= 0 || N <= 0 || K <= 0) return -1;
+    const int eff = effective_splitk(K, splitk);
+    return (eff > 1 || (flags & MFC_GEMM_GELU)) ? (int64_t)eff * M * N : 0;
+}
 
 extern "C" int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
                         const void* A, int64_t lda, const void* B, int64_t ldb,
@@ -855,9 +879,7 @@ int gemm_impl(int dtype, int flags, int64_t M, int64_t N, int64_t K, const void*
             return mfc_launch_status();
         }
     }
-    if (use_ws) {
-        if (hipMemsetAsync(ws, 0, (size_t)M * N * sizeof(float), st) != hipSuccess) return MFC_EHIP;
-    }
+    g.ws_slab = M * N;     // every (row < M, col < N) of every slab is written by exactly one workgroup: no memset
     int rc = dtype == MFC_F32 ? launch<float>(flags, g, bk, splitk, gelu, act_rows, st)
                               : launch<u16>(flags, g, bk, splitk, gelu, act_rows, st);
     if (!rc && ln_tan) {

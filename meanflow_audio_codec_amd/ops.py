@@ -36,8 +36,11 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a=False, trans_b=False, bias
         bias_rows = M
     if act_rows is None:
         act_rows = M
-    if (splitk > 1 or gelu) and ws is None:
-        ws = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    if (splitk > 1 or gelu):
+        need = int(_lib.lib().mfc_gemm_ws_elems(flags, M, N, K, int(splitk)))   # one [M, N] slab per K slice
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 1), dtype=torch.float32, device=A.device)
+        assert ws.dtype == torch.float32 and ws.is_contiguous()
     if residual is not None:
         assert residual.shape == (M, N) and residual.dtype == A.dtype and residual.stride(1) == 1
     rc = _lib.lib().mfc_gemm(
@@ -125,6 +128,24 @@ def ln16(x, want_rstd=True):
     return y, rstd
 
 
+_cnx_ws_cache: dict = {}
+
+
+def cnx_workspace(R: int, s: int, device) -> torch.Tensor:
+    """The partial-sum workspace of the ConvNeXt kernels (``mfc_cnx_ws_elems`` floats): one buffer per device, grown
+    on demand, shared by every call -- launches on one stream are ordered, and each call consumes its records before
+    it returns control to the next launch (the fixed-order reductions run inside the same C call)."""
+    need = int(_lib.lib().mfc_cnx_ws_elems(R, s))
+    if need <= 0:
+        raise _lib.MfcError(f"mfc_cnx_ws_elems({R}, {s}) failed")
+    key = (torch.device(device), torch.cuda.current_stream(device).cuda_stream)
+    t = _cnx_ws_cache.get(key)
+    if t is None or t.numel() < need:
+        t = torch.empty(need, dtype=torch.float32, device=device)
+        _cnx_ws_cache[key] = t
+    return t
+
+
 def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, shiftdot=None, out=None,
                 outdot=None):
     """o = ConvNeXtBlock(FiLM(h1)) on [R, s, s, 16] where ``h0`` holds h1 = LN(h0) and ``h0dot`` the
@@ -144,13 +165,14 @@ def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, sh
     st = _lib.stream_ptr()
     ps = _cnx_struct(w)
     dev = h0.device
-    S = torch.zeros((2 if jvp else 1, R, 32), dtype=torch.float32, device=dev)
+    S = torch.empty((2 if jvp else 1, R, 32), dtype=torch.float32, device=dev)
+    ws = cnx_workspace(R, s, dev)
     G = torch.empty((R, 32), dtype=torch.float32, device=dev)
     q = torch.empty_like(G)
     qd = torch.empty_like(G) if jvp else None
     _lib.check(L.mfc_cnx_stats(dt, R, s, h0.data_ptr(), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
                                _lib.ptr(scaledot), _lib.ptr(shiftdot), ctypes.byref(ps), S[0].data_ptr(),
-                               S[1].data_ptr() if jvp else None, st), "mfc_cnx_stats")
+                               S[1].data_ptr() if jvp else None, ws.data_ptr(), st), "mfc_cnx_stats")
     _lib.check(L.mfc_grn_finalize(R, S[0].data_ptr(), S[1].data_ptr() if jvp else None, G.data_ptr(),
                                   q.data_ptr(), _lib.ptr(qd), st), "mfc_grn_finalize")
     o = out if out is not None else torch.empty_like(h0)
@@ -177,24 +199,25 @@ def cnx_backward(h0, scale, shift, w: dict, s: int, G, q, dout, grads: dict, dh0
     st = _lib.stream_ptr()
     ps, gs = _cnx_struct(w), _cnx_struct(grads)
     dev = h0.device
-    dq = torch.zeros((R, 32), dtype=torch.float32, device=dev)
+    dq = torch.empty((R, 32), dtype=torch.float32, device=dev)
     kG = torch.empty_like(dq)
+    ws = cnx_workspace(R, s, dev)
     _lib.check(L.mfc_cnx_bwd_stats(dt, R, s, h0.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctypes.byref(ps),
-                                   q.data_ptr(), dout.data_ptr(), dq.data_ptr(), st),
+                                   q.data_ptr(), dout.data_ptr(), dq.data_ptr(), ws.data_ptr(), st),
                "mfc_cnx_bwd_stats")
     _lib.check(L.mfc_grn_bwd_finalize(R, G.data_ptr(), dq.data_ptr(), kG.data_ptr(),
                                       grads["grn_gamma"].data_ptr(), st), "mfc_grn_bwd_finalize")
     dc1 = scratch if scratch is not None else torch.empty_like(h0)
     _lib.check(L.mfc_cnx_bwd_main(dt, R, s, h0.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctypes.byref(ps),
                                   q.data_ptr(), kG.data_ptr(), dout.data_ptr(), dc1.data_ptr(), ctypes.byref(gs),
-                                  st), "mfc_cnx_bwd_main")
+                                  ws.data_ptr(), st), "mfc_cnx_bwd_main")
     if dh0 is None:
         dh0 = torch.empty_like(h0)
-    dsc = torch.zeros((R, 16), dtype=torch.float32, device=dev)
-    dsh = torch.zeros_like(dsc)
+    dsc = torch.empty((R, 16), dtype=torch.float32, device=dev)
+    dsh = torch.empty_like(dsc)
     _lib.check(L.mfc_cnx_bwd_conv(dt, R, s, h0.data_ptr(), rho0.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctypes.byref(ps),
                                   dc1.data_ptr(), dout.data_ptr(), dh0.data_ptr(), ctypes.byref(gs),
-                                  dsc.data_ptr(), dsh.data_ptr(), st), "mfc_cnx_bwd_conv")
+                                  dsc.data_ptr(), dsh.data_ptr(), ws.data_ptr(), st), "mfc_cnx_bwd_conv")
     return dh0, dsc, dsh
 
 
@@ -320,10 +343,12 @@ def flow_loss(u, target, *, dudt=None, n_tan=0, t=None, r=None, kind=0, mode=0, 
     seed = torch.empty(B, dtype=torch.float32, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev)
     du = torch.empty_like(u) if want_grad else None
+    ws = torch.empty(B * 256, dtype=torch.float32, device=dev)      # MFC_FLOW_LOSS_WS_PER_ROW partial sums per example
     _lib.check(_lib.lib().mfc_flow_loss(_lib.dtype_code(u.dtype), kind, mode, B, B if Bglobal is None else Bglobal,
                                         D, u.data_ptr(), _lib.ptr(dudt), n_tan, _lib.ptr(t), _lib.ptr(r),
                                         target.data_ptr(), float(p), float(c), pe.data_ptr(), seed.data_ptr(),
-                                        loss.data_ptr(), _lib.ptr(du), _lib.stream_ptr()), "mfc_flow_loss")
+                                        loss.data_ptr(), _lib.ptr(du), ws.data_ptr(), _lib.stream_ptr()),
+               "mfc_flow_loss")
     return loss, du, pe
 
 

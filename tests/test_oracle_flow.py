@@ -40,12 +40,17 @@ def test_boundary_condition_t_equals_r(kind):
         params, apply, D = _mlp_params(8), fo.mlp_flow_apply, 8
     else:
         params, apply, D = _conv_params(64), fo.conv_flow_apply, 64
-    x = torch.randn(B, D, generator=g)
+    x = torch.zeros(B, D) if kind == "mlp" else torch.randn(B, D, generator=g)   # the reference's x: zeros (:44)
     e = torch.randn(B, D, generator=g)
     t = torch.rand(B, 1, generator=g)
     r = t.clone()
     v, u, dudt, v_pred, target = fo.imf_parts(apply, None, params, x, e, t, r)
     assert torch.allclose(v_pred, u, atol=1e-6)
+    # the reference's helper normalises the tangent (v / (||v|| + 1e-6) per row, :23): same property
+    z = fo.linear_interpolate(x, e, t)
+    v_dir = v / (v.norm(dim=-1, keepdim=True) + 1e-6)
+    u2, _, v_pred2 = fo.imf_core(lambda z_, t_, r_: apply(params, z_, torch.cat([t_, t_ - r_], -1), None), v_dir, z, t, r)
+    assert torch.allclose(v_pred2, u2, rtol=1e-6, atol=1e-6) and torch.allclose(u2, u, atol=1e-12)
     # and with h = 0 the u-pass equals the v-pass
     assert torch.allclose(u, v, atol=1e-12)
 
@@ -58,11 +63,13 @@ def test_jvp_matches_reverse_mode(kind):
         params, apply, D = _mlp_params(6), fo.mlp_flow_apply, 6
     else:
         params, apply, D = _conv_params(49), fo.conv_flow_apply, 49
-    z = torch.randn(B, D, generator=g)
+    x = torch.randn(B, D, generator=g)
+    e = torch.randn(B, D, generator=g)
     t = torch.rand(B, 1, generator=g)
     r = 0.5 * t
-    v = torch.randn(B, D, generator=g)
-    v = v / v.norm()
+    z = fo.linear_interpolate(x, e, t)                       # noised = (1-t) x + (0.001 + 0.999 t) noise (:77)
+    v = apply(params, z, torch.cat([t, torch.zeros_like(t)], -1), None)
+    v = (v / (v.norm(dim=-1, keepdim=True) + 1e-6)).detach()  # v_dir (:86-87)
 
     def u_fn(z_, t_, r_):
         return apply(params, z_, torch.cat([t_, t_ - r_], -1), None)
