@@ -24,8 +24,14 @@
 // HBM-bound: algorithmic bytes/clip = 4T + 4 n_frames N (fwd),
 // 4 n_frames N + 4 out_len (inv) -- SURVEY 8(d).
 #include "mfc_common.h"
+#include <cstdlib>
 
 #define MDCT_THREADS 256
+
+// mdct512.hip: the N = 512 kernels (register-resident 16 x 16 FFT); MFC_ENOSYS = shape not covered, take the generic path
+int mfc_mdct512_fwd(const float* x, int64_t B, int64_t T, int64_t ldx, int hop, int64_t nf, float* X, hipStream_t st);
+int mfc_mdct512_inv(const float* X, int64_t B, int64_t nf, int hop, int64_t out_len, float* y, int64_t ldy,
+                    hipStream_t st);
 
 namespace {
 
@@ -315,6 +321,10 @@ mdct_inv_direct_kernel(const float* __restrict__ X, int64_t B, int64_t nf, int N
 }
 
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+inline bool generic_only() {      // MFC_MDCT_GENERIC=1: skip the N = 512 kernels (A/B and cross-check hook)
+    static const bool on = [] { const char* e = getenv("MFC_MDCT_GENERIC"); return e && e[0] == '1'; }();
+    return on;
+}
 
 const size_t MDCT_LDS_CAP = 150 * 1024;
 
@@ -341,6 +351,10 @@ extern "C" int mfc_mdct_fwd(const float* x, int64_t B, int64_t T, int64_t ldx, i
     if (B <= 0 || T <= 0 || N <= 0 || hop <= 0 || ldx < T) return MFC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int64_t nf = mfc_mdct_num_frames(T, N, hop);
+    if (N == 512 && !generic_only()) {
+        const int rc = mfc_mdct512_fwd(x, B, T, ldx, hop, nf, X, st);
+        if (rc != MFC_ENOSYS) return rc;
+    }
     if (is_pow2(N) && N >= 8) {
         // frames per workgroup: ~2048 complex points, span must fit LDS
         int F = 4096 / N;
@@ -375,6 +389,10 @@ extern "C" int mfc_mdct_inv(const float* X, int64_t B, int64_t n_frames, int N, 
     const int64_t out_len = mfc_mdct_out_len(n_frames, N, hop);
     if (ldy < out_len) return MFC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (N == 512 && !generic_only()) {
+        const int rc = mfc_mdct512_inv(X, B, n_frames, hop, out_len, y, ldy, st);
+        if (rc != MFC_ENOSYS) return rc;
+    }
     if (is_pow2(N) && N >= 8) {
         constexpr int OPT = 4;
         const int SP = MDCT_THREADS * OPT;

@@ -19,6 +19,9 @@ D, CD, LAT, NB = 392704, 128, 256, 8
 @pytest.fixture(scope="module")
 def literal_state():
     from meanflow_audio_codec_amd.models import ConditionalConvFlow, TrainState, adamw
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()          # blocks cached by earlier tests are not "free" to mem_get_info
     free, total = torch.cuda.mem_get_info()
     if free < 230 * 2 ** 30:
         pytest.skip(f"needs ~230 GiB of free HBM, found {free / 2**30:.0f} GiB")

@@ -55,6 +55,43 @@ def test_pow2_windows_vs_oracle(N, hop, T, B):
     assert np.abs(xr - xr64).max() <= 3e-5 * max(1.0, np.abs(xr64).max())
 
 
+@pytest.mark.parametrize("hop,T,B", [(256, 196608, 3), (256, 100, 2), (256, 784, 5), (256, 40001, 2), (512, 30000, 2),
+                                     (128, 9000, 3), (384, 12345, 2), (64, 5000, 1), (4, 3000, 1), (260, 7000, 2),
+                                     (256, 16 * 256 + 512, 1), (256, 17 * 256 + 512, 2), (256, 96 * 256 + 512, 2),
+                                     (256, 97 * 256 + 512, 1)])
+def test_n512_kernels_vs_oracle(hop, T, B):
+    """The N = 512 kernels (csrc/mdct512.hip: register-resident 16 x 16 FFT, LDS overlap-add with carry) against the
+    float64 oracle: power-of-two and other hops, hop == N, clips shorter than a window, frame counts around the
+    16-frame iteration and the 96-frame segment boundaries, and rows that are NOT 16-byte aligned (views into a wider
+    buffer with an odd leading dimension: the scalar-load variant of the forward kernel)."""
+    from meanflow_audio_codec_amd import _lib
+    from meanflow_audio_codec_amd.preprocessing import imdct, mdct
+    rng = np.random.default_rng(hop * 7 + T)
+    x = rng.standard_normal((B, T)).astype(np.float32)
+    X64 = o.mdct_f64(x, 512, hop)
+    X = mdct(_dev(x), 512, hop).cpu().numpy()
+    assert X.shape == X64.shape
+    assert np.abs(X - X64).max() <= 2e-5 * max(1.0, np.abs(X64).max())
+    xr64 = o.imdct_f64(X64.astype(np.float32), 512, hop)
+    xr = imdct(_dev(X64.astype(np.float32)), 512, hop).cpu().numpy()
+    assert xr.shape == xr64.shape
+    assert np.abs(xr - xr64).max() <= 2e-5 * max(1.0, np.abs(xr64).max())
+    # unaligned rows through the C ABI: ldx = T + 3 (forward), ldy = out_len + 1 (inverse)
+    L = _lib.lib()
+    wide = torch.zeros(B, T + 3, device="cuda")
+    wide[:, :T] = _dev(x)
+    nf = X64.shape[1]
+    Xo = torch.empty(B, nf, 512, device="cuda")
+    _lib.check(L.mfc_mdct_fwd(wide.data_ptr() + 0, B, T, T + 3, 512, hop, Xo.data_ptr(), _lib.stream_ptr()), "fwd")
+    assert np.abs(Xo.cpu().numpy() - X64).max() <= 2e-5 * max(1.0, np.abs(X64).max())
+    out_len = xr64.shape[1]
+    yo = torch.full((B, out_len + 1), 7.0, device="cuda")
+    Xin = _dev(X64.astype(np.float32))
+    _lib.check(L.mfc_mdct_inv(Xin.data_ptr(), B, nf, 512, hop, yo.data_ptr(), out_len + 1, _lib.stream_ptr()), "inv")
+    assert np.abs(yo[:, :out_len].cpu().numpy() - xr64).max() <= 2e-5 * max(1.0, np.abs(xr64).max())
+    assert bool((yo[:, out_len] == 7.0).all())           # nothing written past a row
+
+
 @pytest.mark.parametrize("N,hop,T", [(576, 288, 5000), (12, 6, 100), (7, 3, 50), (100, 50, 777)])
 def test_non_pow2_windows_direct_kernel(N, hop, T):
     """The reference's default window is 576 (mdct.py DEFAULT_WINDOW_SIZE)."""
