@@ -1411,13 +1411,20 @@ __global__ void grn_bwd_finalize_kernel(int64_t R, const float* G, const float* 
     const float dG = d * inv - sdg * inv * inv * (1.0f / 32.0f);
     kG[r * 32 + c] = g > 0.f ? dG / g : 0.f;
 }
-// dgamma[c] += sum_r dq[r][c], rows in ascending order (fixed order; R is a batch size)
-__global__ void grn_dgamma_kernel(int64_t R, const float* dq, float* dgamma) {
-    const int c = threadIdx.x;
-    if (c >= 32) return;
+// dgamma[c] += sum_r dq[r][c]: fixed-shape tree (8 row groups r = g, g + 8, ... ascending, then groups in order)
+__global__ void __launch_bounds__(256) grn_dgamma_kernel(int64_t R, const float* dq, float* dgamma) {
+    __shared__ float part[8][32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     float v = 0.f;
-    for (int64_t r = 0; r < R; ++r) v += dq[r * 32 + c];
-    dgamma[c] += v;
+    for (int64_t r = g; r < R; r += 8) v += dq[r * 32 + c];
+    part[g][c] = v;
+    __syncthreads();
+    if (g == 0) {
+        float sum = part[0][c];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) sum += part[k][c];
+        dgamma[c] += sum;
+    }
 }
 
 inline Dev to_dev(const mfc_cnx_params* p) {
@@ -1530,7 +1537,7 @@ extern "C" int mfc_grn_bwd_finalize(int64_t R, const float* G, const float* dq, 
     const int64_t blocks = ceil_div64(R * 32, 256);
     hipLaunchKernelGGL(grn_bwd_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, R, G,
                        dq, kG, dgamma);
-    hipLaunchKernelGGL(grn_dgamma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, R, dq, dgamma);
+    hipLaunchKernelGGL(grn_dgamma_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, R, dq, dgamma);
     return mfc_launch_status();
 }
 

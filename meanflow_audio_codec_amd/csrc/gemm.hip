@@ -665,6 +665,27 @@ ln16_tangent_kernel(int64_t rows, int64_t groups, T* C, int64_t ldc, int64_t bia
     }
 }
 
+// split-K slab reduction, fixed-shape tree: 16 waves of a workgroup each add the slabs congruent to their index mod 16
+// (ascending; 64 consecutive outputs per wave instruction), then the 16 partial sums are added in wave order and land in
+// slab 0.  Deterministic, and parallel enough for the K = S products (hundreds of slabs over a 128 x 128 output).
+__global__ void __launch_bounds__(1024)
+gemm_slab_reduce_kernel(float* ws, int nslab, int64_t total) {
+    __shared__ float part[16][64];
+    const int il = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t o = blockIdx.x * 64LL + il;
+    float v = 0.f;
+    if (o < total)
+        for (int z = w; z < nslab; z += 16) v += ws[(int64_t)z * total + o];
+    part[w][il] = v;
+    __syncthreads();
+    if (w == 0 && o < total) {
+        float sum = part[0][il];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) sum += part[k][il];
+        ws[o] = sum;
+    }
+}
+
 // split-K / activation epilogue over the fp32 workspace
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -744,6 +765,11 @@ int launch(int flags, GemmArgs g, int bk, int splitk, int gelu, int64_t act_rows
     if (g.ws) {
         int64_t blocks = ceil_div64(g.M * g.N, 256);
         if (blocks > 4096) blocks = 4096;
+        if (splitk > 8) {     // many slabs: tree reduction into slab 0 first (the loop in the epilogue would be serial)
+            hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)ceil_div64(g.M * g.N, 64)), dim3(1024), 0, st, g.ws,
+                               splitk, g.M * g.N);
+            splitk = 1;
+        }
         hipLaunchKernelGGL((gemm_epilogue_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st,
                            (const float*)g.ws, splitk, g.M, g.N, (T*)g.C, g.ldc, g.bias, g.bias_rows, gelu, act_rows,
                            g.alpha, (const T*)g.R, g.ldr, g.beta, g.accum);

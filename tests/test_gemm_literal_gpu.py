@@ -121,10 +121,9 @@ def test_fused_weight_gradient_adamw_at_literal_size(trans):
     assert torch.equal(mb, c1 * gf)
     sl = slice(0, 1 << 22)
     assert torch.allclose(vb.reshape(-1)[sl], (c2 * gf * gf).reshape(-1)[sl], rtol=1e-6, atol=0)
-    del gf
-    torch.cuda.empty_cache()
+
     step = (pb - p0).abs()
-    bound = lr * (1.0 + wd * p0.abs()) * (1.0 + 1e-5) + 1e-12
+    bound = lr * (1.0 + wd * p0.abs()) * (1.0 + 1e-5) + 1.2e-7 * p0.abs() + 1e-12    # + one fp32 ulp of p
     assert bool((step <= bound).all()), (step - bound).max().item()
     # the gradient itself against a chunked fp32 product on sampled columns / rows
     if shape[0] == S:
