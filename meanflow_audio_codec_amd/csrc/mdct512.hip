@@ -240,6 +240,7 @@ __device__ inline void inv_fetch(f32x4 (&pre)[INV_V], const float* Xi, int nfr, 
     }
 }
 
+template <bool HOP256>      // hop == 256 (every shipped config): the overlap-add has a fixed per-thread structure
 __global__ void __launch_bounds__(NT, 3)      // <= 168 VGPRs: three workgroups (= waves per SIMD) per CU
 mdct512_inv_kernel(const float* __restrict__ X, int64_t nf, int hop, int hop_shift, int64_t out_len, int seg_frames,
                    int64_t spc, int64_t n_segs, float* __restrict__ y, int64_t ldy) {
@@ -314,6 +315,35 @@ mdct512_inv_kernel(const float* __restrict__ X, int64_t nf, int hop, int hop_shi
             const int L = (nfr - 1) * hop + 2 * N;
             const int done = nfr * hop;
             const int64_t base = c0 * hop;
+            if constexpr (HOP256) {
+                // p = tid + 256 r and frame i contribute sample n = tid + 256 (r - i) of frame i: for d = r - i in 0..3
+                // the element of u, its sign and the window value depend on the thread only
+                //   d = 0: n < N/2          ->  +u[N/2 + tid]       w[tid]
+                //   d = 1, 2: N/2 <= n < 3N/2 -> -u[3N/2 - 1 - n]   w[n] / w[2N - 1 - n]
+                //   d = 3: n >= 3N/2        ->  -u[n - 3N/2]        w[2N - 1 - n]
+                const float w0 = l.win[tid], w1 = -l.win[tid + 256], w2 = -l.win[N - 1 - tid], w3 = -l.win[255 - tid];
+                const float* u0 = l.ex + (N / 2 + tid);
+                const float* u1 = l.ex + (N - 1 - tid);          // 3N/2 - 1 - (tid + 256)
+                const float* u2 = l.ex + (N / 2 - 1 - tid);      // 3N/2 - 1 - (tid + 512)
+                const float* u3 = l.ex + tid;                    // (tid + 768) - 3N/2
+                const bool flush_all = last_seg && c0 + nfr == nf;
+                const int nr = nfr + 3;                           // L / 256
+#pragma unroll 4
+                for (int r = 0; r < nr; ++r) {
+                    float s = r < 3 ? carry_in[tid + 256 * r] : 0.f;          // CL = 768
+                    // ascending frame order i = r-3 .. r
+                    if (r >= 3 && r - 3 < nfr) s += w3 * u3[(r - 3) * N];
+                    if (r >= 2 && r - 2 < nfr) s += w2 * u2[(r - 2) * N];
+                    if (r >= 1 && r - 1 < nfr) s += w1 * u1[(r - 1) * N];
+                    if (r < nfr) s += w0 * u0[r * N];
+                    const int64_t gp = base + tid + 256 * r;
+                    if (r < nfr || flush_all) {
+                        if (gp >= own_lo && gp < own_hi) yb[gp] = s;
+                    } else {
+                        carry_out[tid + 256 * (r - nfr)] = s;
+                    }
+                }
+            } else
             for (int p = tid; p < L; p += NT) {
                 float s = p < CL ? carry_in[p] : 0.f;
                 // frames i of this iteration with i * hop <= p < i * hop + 2N  (hop_shift >= 0: hop is a power of two)
@@ -342,6 +372,15 @@ mdct512_inv_kernel(const float* __restrict__ X, int64_t nf, int hop, int hop_shi
     }
 }
 
+// workgroups that are resident at once (persistent grids: more would run as a second, partly idle round)
+inline int64_t resident_blocks(const void* kern, size_t lds) {
+    int dev = 0, cus = 256, per_cu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, lds) != hipSuccess || per_cu < 1) per_cu = 2;
+    return (int64_t)cus * per_cu;
+}
+
 inline size_t lds_bytes(int extra_floats) {
     return (size_t)(2 * M + 256) * sizeof(float2) + (size_t)(N + EX_FLOATS + extra_floats) * sizeof(float);
 }
@@ -356,10 +395,11 @@ int mfc_mdct512_fwd(const float* x, int64_t B, int64_t T, int64_t ldx, int hop, 
     if (hop < 4 || hop > N || (hop & 3)) return MFC_ENOSYS;
     const bool vec = (((uintptr_t)x & 15) == 0) && ((ldx & 3) == 0);
     const int64_t gpc = ceil_div64(nf, F), n_groups = gpc * B;
-    const int64_t grid = n_groups < 1024 ? n_groups : 1024;
     const size_t lds = lds_bytes(0);
     auto go = [&](auto kern) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int64_t slots = resident_blocks((const void*)kern, lds);
+        const int64_t grid = n_groups < slots ? n_groups : slots;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, x, T, ldx, hop, nf, gpc, n_groups, X);
     };
     const bool small = ((F - 1) * hop + 2 * N) / 4 <= 5 * NT;
@@ -372,17 +412,27 @@ int mfc_mdct512_inv(const float* X, int64_t B, int64_t nf, int hop, int64_t out_
                     hipStream_t st) {
     using namespace m512;
     if (hop < 4 || hop > N || ((uintptr_t)X & 15)) return MFC_ENOSYS;
-    // segment length: enough segments to fill the chip (~4 workgroups per CU), at least 2 iterations each so the lead-in
-    // frames stay a small fraction
-    int seg = 96;
-    while (seg > 2 * F && ceil_div64(nf, seg) * B < 1024) seg -= F;
-    const int64_t spc = ceil_div64(nf, seg), n_segs = spc * B;
-    const int64_t grid = n_segs < 1024 ? n_segs : 1024;
+    const int lead = (2 * N + hop - 1) / hop - 1;
     const size_t lds = lds_bytes(2 * (2 * N - hop));
-    (void)hipFuncSetAttribute((const void*)mdct512_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const bool h256 = hop == 256;
+    const void* kern = h256 ? (const void*)mdct512_inv_kernel<true> : (const void*)mdct512_inv_kernel<false>;
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int64_t slots = resident_blocks(kern, lds);
+    // segment = own frames of one workgroup visit; own + lead-in frames = a whole number of 16-frame iterations.  Three
+    // iterations per segment keep the lead-in recompute at lead/48 and give every resident workgroup several segments.
+    int iters = 3;
+    while (iters * F <= lead) ++iters;
+    int seg = iters * F - lead;
+    while (iters > 1 && ceil_div64(nf, seg) * B < slots && (iters - 1) * F > lead) { --iters; seg = iters * F - lead; }
+    const int64_t spc = ceil_div64(nf, seg), n_segs = spc * B;
+    const int64_t grid = n_segs < slots ? n_segs : slots;
     int hop_shift = -1;
     if ((hop & (hop - 1)) == 0) for (hop_shift = 0; (1 << hop_shift) < hop; ++hop_shift) {}
-    hipLaunchKernelGGL(mdct512_inv_kernel, dim3((unsigned)grid), dim3(NT), lds, st, X, nf, hop, hop_shift, out_len, seg,
-                       spc, n_segs, y, ldy);
+    if (h256)
+        hipLaunchKernelGGL(mdct512_inv_kernel<true>, dim3((unsigned)grid), dim3(NT), lds, st, X, nf, hop, hop_shift, out_len,
+                           seg, spc, n_segs, y, ldy);
+    else
+        hipLaunchKernelGGL(mdct512_inv_kernel<false>, dim3((unsigned)grid), dim3(NT), lds, st, X, nf, hop, hop_shift, out_len,
+                           seg, spc, n_segs, y, ldy);
     return mfc_launch_status();
 }
