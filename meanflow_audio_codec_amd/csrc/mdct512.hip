@@ -99,9 +99,10 @@ __device__ inline void init_tables(const Lds& l, int tid) {
 __device__ inline void fft256(float2 (&z)[16], const float2* wjt, float* ex, int f, int j) {
     fft16(z);
     float2* exf = (float2*)ex + f * EX_FRAME;
-    float2* exj = exf + j;
-    const float2* wj = wjt + j;
-    asm volatile("" : "+v"(exj), "+v"(wj));
+    int oE = f * EX_FRAME + j, oW = j;
+    asm volatile("" : "+v"(oE), "+v"(oW));
+    float2* exj = (float2*)ex + oE;
+    const float2* wj = wjt + oW;
 #pragma unroll
     for (int k = 0; k < 16; ++k) exj[k * EX_ROW] = k == 0 ? z[0] : cmul(z[k], wj[16 * k]);
     __syncthreads();
@@ -180,13 +181,15 @@ mdct512_fwd_kernel(const float* __restrict__ x, int64_t T, int64_t ldx, int hop,
         {
             // every index below is (a per-lane base) + (a compile-time constant): two sample bases, two window bases and
             // one twiddle base per lane, the rest folds into the DS instructions' offset fields
-            const float* fr = span + f * hop;
-            const float* pA = fr + 2 * j;          // pA[c] = fr[c + 2j]
-            const float* pB = fr - 2 * j;          // pB[c] = fr[c - 2j]   (every c used below keeps c - 2j >= 0)
-            const float* wA_ = l.win + 2 * j;
-            const float* wB_ = l.win - 2 * j;
-            const float2* twj = l.tw + j;
-            asm volatile("" : "+v"(pA), "+v"(pB), "+v"(wA_), "+v"(wB_), "+v"(twj));
+            // (the laundered quantities are INDICES, not pointers: an asm-laundered pointer loses its LDS address space
+            // and every access through it becomes a flat_load)
+            int oA = f * hop + 2 * j, oB = f * hop - 2 * j, oWA = 2 * j, oWB = -2 * j, oT = j;
+            asm volatile("" : "+v"(oA), "+v"(oB), "+v"(oWA), "+v"(oWB), "+v"(oT));
+            const float* pA = span + oA;           // pA[c] = fr[c + 2j]
+            const float* pB = span + oB;           // pB[c] = fr[c - 2j]   (every c used below keeps c - 2j >= 0)
+            const float* wA_ = l.win + oWA;
+            const float* wB_ = l.win + oWB;
+            const float2* twj = l.tw + oT;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {         // m = j + 16 i
                 float re, im;
@@ -207,10 +210,11 @@ mdct512_fwd_kernel(const float* __restrict__ x, int64_t T, int64_t ldx, int hop,
         __syncthreads();                       // every lane has read its exchange row: the row image may be written
         // post-twiddle: W = Z[k] e^{-i pi (k + 1/4) / N};  X[2k] = Re W, X[N-1-2k] = -Im W
         {
-            float* rA = l.ex + f * N + 2 * j;       // rA[c] = rows[c + 2j]
-            float* rB = l.ex + f * N - 2 * j;       // rB[c] = rows[c - 2j]
-            const float2* tpj = l.twp + j;
-            asm volatile("" : "+v"(rA), "+v"(rB), "+v"(tpj));
+            int oA = f * N + 2 * j, oB = f * N - 2 * j, oT = j;
+            asm volatile("" : "+v"(oA), "+v"(oB), "+v"(oT));
+            float* rA = l.ex + oA;                  // rA[c] = rows[c + 2j]
+            float* rB = l.ex + oB;                  // rB[c] = rows[c - 2j]
+            const float2* tpj = l.twp + oT;
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {       // k = j + 16 k2
                 const float2 W = cmul(z[k2], tpj[16 * k2]);
@@ -281,10 +285,11 @@ mdct512_inv_kernel(const float* __restrict__ X, int64_t nf, int hop, int hop_shi
             // z[m] = (X[2m] + i X[N-1-2m]) e^{-i pi m / N}
             float2 z[16];
             {
-                const float* xA = rows + f * N + 2 * j;
-                const float* xB = rows + f * N - 2 * j;
-                const float2* twj = l.tw + j;
-                asm volatile("" : "+v"(xA), "+v"(xB), "+v"(twj));
+                int oA = f * N + 2 * j, oB = f * N - 2 * j, oT = j;
+                asm volatile("" : "+v"(oA), "+v"(oB), "+v"(oT));
+                const float* xA = rows + oA;
+                const float* xB = rows + oB;
+                const float2* twj = l.tw + oT;
 #pragma unroll
                 for (int i = 0; i < 16; ++i)      // m = j + 16 i
                     z[i] = cmul(make_float2(xA[32 * i], xB[N - 1 - 32 * i]), twj[16 * i]);
@@ -298,10 +303,11 @@ mdct512_inv_kernel(const float* __restrict__ X, int64_t nf, int hop, int hop_shi
             __syncthreads();
             // u = (2/N) DCT-IV(X):  u[2k] = s Re W, u[N-1-2k] = -s Im W
             {
-                float* uA = l.ex + f * N + 2 * j;
-                float* uB = l.ex + f * N - 2 * j;
-                const float2* tpj = l.twp + j;
-                asm volatile("" : "+v"(uA), "+v"(uB), "+v"(tpj));
+                int oA = f * N + 2 * j, oB = f * N - 2 * j, oT = j;
+                asm volatile("" : "+v"(oA), "+v"(oB), "+v"(oT));
+                float* uA = l.ex + oA;
+                float* uB = l.ex + oB;
+                const float2* tpj = l.twp + oT;
 #pragma unroll
                 for (int k2 = 0; k2 < 16; ++k2) {     // k = j + 16 k2
                     const float2 W = cmul(z[k2], tpj[16 * k2]);

@@ -125,7 +125,8 @@ class ComprehensiveEvaluator:
             "nfe_results": {},
         }
         real_data = np.asarray(real_data.detach().cpu() if isinstance(real_data, torch.Tensor) else real_data)
-        latents = torch.zeros(batch_size, cfg.latent_dimension, dtype=torch.float32, device=self.device)
+        shape = tuple(getattr(self.state.model, "latent_shape", (cfg.latent_dimension,)))
+        latents = torch.zeros((batch_size,) + shape, dtype=torch.float32, device=self.device)
         sweep = [(str(n), int(n)) for n in n_steps_list] + ([("1nfe", 0)] if one_step else [])
         key = PRNGKey(seed)
         for label, n_steps in sweep:

@@ -137,6 +137,11 @@ class ConditionalConvFlow:
             ctx.enc = (xt, a, g32)
         return lat
 
+    @property
+    def latent_shape(self) -> tuple:
+        """Per-sample shape of the latents ``encode`` returns and ``latent_proj`` is sized for."""
+        return (self.latent_input_dim,)
+
     def conditioning(self, w: dict, t: torch.Tensor, h: torch.Tensor, latents: torch.Tensor | None,
                      want_dot: bool = False):
         """cond = emb(t) + emb(h) (+ latent_proj(flatten(latents))), models/conv_flow.py:257-267; the

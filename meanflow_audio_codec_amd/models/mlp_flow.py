@@ -77,6 +77,11 @@ class ConditionalFlow:
             ctx.enc = (xt, a, g)
         return lat
 
+    @property
+    def latent_shape(self) -> tuple:
+        """Per-sample shape of the latents ``encode`` returns (what ``sample`` callers must feed)."""
+        return (self.latent_dimension,)
+
     def conditioning(self, w: dict, t, h, latents, want_dot: bool = False):
         """cond = emb(t) + emb(h) (models/mlp_flow.py:181-183); latents enter by concatenation, not here."""
         return ops.time_embed(t.reshape(-1).contiguous(), h.reshape(-1).contiguous(), self.condition_dimension,

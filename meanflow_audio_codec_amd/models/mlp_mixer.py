@@ -171,6 +171,11 @@ class ConditionalMLPMixerFlow:
             ctx.enc = (xt, cond, saved)
         return lat
 
+    @property
+    def latent_shape(self) -> tuple:
+        """Per-sample shape of the latents ``encode`` returns and ``latent_proj`` is sized for."""
+        return (self.num_latent_tokens, self.latent_dimension)
+
     def conditioning(self, w: dict, t, h, latents, want_dot: bool = False):
         add = None
         if latents is not None:

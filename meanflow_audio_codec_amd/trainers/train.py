@@ -256,7 +256,9 @@ def train_flow(config, data_iterator=None, *, resume: bool = False, n_steps: int
     def draw_samples(step):
         from ..evaluators.sampling import sample
         B = config.batch_size
-        latents = torch.zeros(B, config.latent_dimension, dtype=torch.float32, device=device)   # train.py:360-364
+        # train.py:360-364 feeds zeros [B, latent_dimension]; the Mixer's latent_proj is sized for its encoder's
+        # [B, 32, latent] output (the reference would fail Flax's shape check there), so the zeros take the model's shape
+        latents = torch.zeros((B,) + tuple(model.latent_shape), dtype=torch.float32, device=device)
         smps = sample(state.apply_fn, D, state.work, PRNGKey(config.sample_seed), latents=latents,
                       n_steps=config.sample_steps, use_improved_mean_flow=config.use_improved_mean_flow,
                       guidance_scale=1.0)
