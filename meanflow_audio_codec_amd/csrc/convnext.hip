@@ -58,6 +58,8 @@ struct DevG {
 // LDS accesses of one wave execute in order, so a wave reading back its own scratch needs no s_waitcnt between
 // the writes and the reads -- only the compiler must not reorder them
 __device__ inline void lds_fence() { asm volatile("" ::: "memory"); }
+// >= 5 wait states between dependent MFMAs of different shapes (see chain_row); s_nop 7 = 8 wait states
+__device__ inline void mfma_shape_fence(f32x4& a, f32x4& b) { asm volatile("s_nop 7" : "+v"(a), "+v"(b)); }
 // make a just-loaded value land HERE: left pending, the compiler's wait for it would sit at its first use in
 // the tile loop's common path and (vmcnt being one in-order counter) drain the halo DMA on every tile
 __device__ inline void land(const float& v) { asm volatile("" ::"v"(v)); }
@@ -449,6 +451,7 @@ template <typename T, bool JVP, bool K32W = false> struct RowW {
                 mma16(bd, w0, shdf);
             }
         }
+        if constexpr (K32) mfma_shape_fence(b, bd);   // b / bd (K16 results) become SrcC of K = 32 steps in chain_row
         if constexpr (K32) {
             // lane (q, m) of pair p: tap 2p + (q >> 1), input channels 8 (q & 1) .. +7, output channel m -- two of the
             // stashed K16 fragments (lane groups 2 (q & 1) and 2 (q & 1) + 1 of that tap, same m)
@@ -510,11 +513,14 @@ __device__ inline void chain_row(const T* tile, const T* tiled, const T* wc0, co
                 mma16(acc, w0, in ? rw.shf : z);
                 if constexpr (JVP) mma16(accd, w0, in ? rw.shdf : z);
             }
-        // The K = 32 steps below continue these accumulators.  hipcc (ROCm 7.2) does not separate dependent MFMAs of
-        // different shapes correctly: a 16x16x32 result consumed as the accumulator of a 16x16x16 step gave wrong rows
-        // (which is why tap 8 is a zero-padded K = 32 step too).  This direction tested clean; the wait is insurance
-        // and only border tiles pay it.
-        if constexpr (K32W && sizeof(T) == 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        // The K = 32 steps below continue these accumulators.  TOOLCHAIN HAZARD (root-caused in
+        // tools/probe/mfma_mixed_shape.hip, measured on MI355X / ROCm 7.2): a dependent MFMA whose SrcC is the result
+        // of an MFMA of a DIFFERENT shape (16x16x16 -> 16x16x32 or the reverse) needs >= 5 wait states in between;
+        // hipcc emits none for that pair (it does for nothing else in this file: same-shape accumulate chains are
+        // interlocked by the hardware), and the back-to-back pair returns wrong rows.  MFMA_SHAPE_FENCE supplies the
+        // wait states as an asm statement that NAMES the accumulators, so the compiler cannot move either MFMA across it.
+        // (This is also why tap 8 is a zero-padded K = 32 step: no K32 -> K16 link exists anywhere.)
+        if constexpr (K32W && sizeof(T) == 2) mfma_shape_fence(acc, accd);
     }
     if constexpr (K32W && sizeof(T) == 2) {
         const int band = y * (Halo<T>::CPP * HW * Halo<T>::EPC);

@@ -247,7 +247,7 @@ __device__ inline void inv_fetch(f32x4 (&pre)[INV_V], const float* Xi, int nfr, 
 template <bool HOP256>      // hop == 256 (every shipped config): the overlap-add has a fixed per-thread structure
 __global__ void __launch_bounds__(NT, 3)      // <= 168 VGPRs: three workgroups (= waves per SIMD) per CU
 mdct512_inv_kernel(const float* __restrict__ X, int64_t nf, int hop, int hop_shift, int64_t out_len, int seg_frames,
-                   int64_t spc, int64_t n_segs, float* __restrict__ y, int64_t ldy) {
+                   int64_t spc, int64_t n_segs, float* __restrict__ y, int64_t ldy, int vec_y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, f = tid >> 4, j = tid & 15;
     const Lds l = carve(smem);
@@ -322,31 +322,49 @@ mdct512_inv_kernel(const float* __restrict__ X, int64_t nf, int hop, int hop_shi
             const int done = nfr * hop;
             const int64_t base = c0 * hop;
             if constexpr (HOP256) {
-                // p = tid + 256 r and frame i contribute sample n = tid + 256 (r - i) of frame i: for d = r - i in 0..3
-                // the element of u, its sign and the window value depend on the thread only
-                //   d = 0: n < N/2          ->  +u[N/2 + tid]       w[tid]
-                //   d = 1, 2: N/2 <= n < 3N/2 -> -u[3N/2 - 1 - n]   w[n] / w[2N - 1 - n]
-                //   d = 3: n >= 3N/2        ->  -u[n - 3N/2]        w[2N - 1 - n]
-                const float w0 = l.win[tid], w1 = -l.win[tid + 256], w2 = -l.win[N - 1 - tid], w3 = -l.win[255 - tid];
-                const float* u0 = l.ex + (N / 2 + tid);
-                const float* u1 = l.ex + (N - 1 - tid);          // 3N/2 - 1 - (tid + 256)
-                const float* u2 = l.ex + (N / 2 - 1 - tid);      // 3N/2 - 1 - (tid + 512)
-                const float* u3 = l.ex + tid;                    // (tid + 768) - 3N/2
+                // A thread owns 4 consecutive samples p = 4 tid + e + 1024 R (16-byte LDS reads and global stores).  Their
+                // 256-sample block r = 4 R + (tid >> 6) is wave-uniform; with t = 4 (tid & 63) + e the position inside
+                // the block, frame i = r - d contributes its sample n = t + 256 d:
+                //   d = 0:  +u[256 + t] w[t]         d = 1:  -u[511 - t] w[256 + t]
+                //   d = 2:  -u[255 - t] w[511 - t]   d = 3:  -u[t] w[255 - t]          (w[n] = w[2N - 1 - n])
+                // added in ascending frame order d = 3, 2, 1, 0 on top of the carry.
+                const int tl = 4 * (tid & 63), blk = tid >> 6;
+                f32x4 w0, w1, w2, w3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    w0[e] = l.win[tl + e]; w1[e] = -l.win[256 + tl + e];
+                    w2[e] = -l.win[511 - tl - e]; w3[e] = -l.win[255 - tl - e];
+                }
                 const bool flush_all = last_seg && c0 + nfr == nf;
-                const int nr = nfr + 3;                           // L / 256
-#pragma unroll 4
-                for (int r = 0; r < nr; ++r) {
-                    float s = r < 3 ? carry_in[tid + 256 * r] : 0.f;          // CL = 768
-                    // ascending frame order i = r-3 .. r
-                    if (r >= 3 && r - 3 < nfr) s += w3 * u3[(r - 3) * N];
-                    if (r >= 2 && r - 2 < nfr) s += w2 * u2[(r - 2) * N];
-                    if (r >= 1 && r - 1 < nfr) s += w1 * u1[(r - 1) * N];
-                    if (r < nfr) s += w0 * u0[r * N];
-                    const int64_t gp = base + tid + 256 * r;
+                const int nr = nfr + 3;                           // 256-sample blocks of the region
+                for (int R = 0; 4 * R + blk < nr; ++R) {
+                    const int r = 4 * R + blk;
+                    f32x4 s = r < 3 ? *reinterpret_cast<const f32x4*>(carry_in + 4 * tid + 1024 * R)      // CL = 768
+                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (r >= 3 && r - 3 < nfr) {
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(l.ex + (r - 3) * N + tl);
+                        s += w3 * u;
+                    }
+                    if (r >= 2 && r - 2 < nfr) {
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(l.ex + (r - 2) * N + 252 - tl);
+                        s += w2 * f32x4{u[3], u[2], u[1], u[0]};
+                    }
+                    if (r >= 1 && r - 1 < nfr) {
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(l.ex + (r - 1) * N + 508 - tl);
+                        s += w1 * f32x4{u[3], u[2], u[1], u[0]};
+                    }
+                    if (r < nfr) {
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(l.ex + r * N + 256 + tl);
+                        s += w0 * u;
+                    }
+                    const int64_t gp = base + 4 * tid + 1024 * R;
                     if (r < nfr || flush_all) {
-                        if (gp >= own_lo && gp < own_hi) yb[gp] = s;
+                        if (gp >= own_lo && gp < own_hi) {
+                            if (vec_y) *reinterpret_cast<f32x4*>(yb + gp) = s;
+                            else { yb[gp] = s[0]; yb[gp + 1] = s[1]; yb[gp + 2] = s[2]; yb[gp + 3] = s[3]; }
+                        }
                     } else {
-                        carry_out[tid + 256 * (r - nfr)] = s;
+                        *reinterpret_cast<f32x4*>(carry_out + 4 * tid + 1024 * R - 256 * nfr) = s;
                     }
                 }
             } else
@@ -434,11 +452,12 @@ int mfc_mdct512_inv(const float* X, int64_t B, int64_t nf, int hop, int64_t out_
     const int64_t grid = n_segs < slots ? n_segs : slots;
     int hop_shift = -1;
     if ((hop & (hop - 1)) == 0) for (hop_shift = 0; (1 << hop_shift) < hop; ++hop_shift) {}
+    const int vec_y = (((uintptr_t)y & 15) == 0 && (ldy & 3) == 0) ? 1 : 0;      // 16-byte output stores legal
     if (h256)
         hipLaunchKernelGGL(mdct512_inv_kernel<true>, dim3((unsigned)grid), dim3(NT), lds, st, X, nf, hop, hop_shift, out_len,
-                           seg, spc, n_segs, y, ldy);
+                           seg, spc, n_segs, y, ldy, vec_y);
     else
         hipLaunchKernelGGL(mdct512_inv_kernel<false>, dim3((unsigned)grid), dim3(NT), lds, st, X, nf, hop, hop_shift, out_len,
-                           seg, spc, n_segs, y, ldy);
+                           seg, spc, n_segs, y, ldy, vec_y);
     return mfc_launch_status();
 }
