@@ -109,8 +109,19 @@ class GraphedDecoder:
         body()                                   # warm-up: allocations, function attributes
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = body()
+        # The cyclic garbage collector must not run inside the capture: collecting an unrelated object that owns device
+        # resources (an older hipGraph, an event) issues HIP calls that are illegal while a stream is capturing and
+        # aborts the process (seen as "Fatal Python error: Aborted ... Garbage-collecting" in a test run).
+        import gc
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.out = body()
+        finally:
+            if was_enabled:
+                gc.enable()
 
     def _draw(self):
         ops_out = ops.randn(self.seed, 0x6400, self.calls * self.B, self.B, self.model.noise_dimension,
