@@ -154,6 +154,21 @@ __device__ inline void ln_fwd_a(const float v[4], float n[4], float& mean, float
 #pragma unroll
     for (int i = 0; i < 4; ++i) n[i] = (v[i] - mean) * rho;
 }
+// The same LayerNorm for an input whose channel mean is already zero (see stash_conv_w: the conv weights and bias are
+// centred over the OUTPUT channels when they are stashed, so the MFMA chain delivers c1 - mean_c(c1) directly and the
+// mean, its subtraction and half of the reduction ladder disappear from the per-pixel VALU work).
+__device__ inline void ln_fwd_centered(const float v[4], float n[4], float& rho) {
+    const float ss = red_q(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+    rho = rsqrtf(ss * (1.0f / 16.0f) + LN_EPS);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) n[i] = v[i] * rho;
+}
+// ... and its tangent for a centred tangent vd (the tangent conv uses the same centred weights): mean(vd) = 0
+__device__ inline void ln_jvp_centered(const float vd[4], const float n[4], float rho, float nd[4]) {
+    const float dot = red_q(n[0] * vd[0] + n[1] * vd[1] + n[2] * vd[2] + n[3] * vd[3]) * (1.0f / 16.0f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nd[i] = rho * (vd[i] - n[i] * dot);
+}
 // tangent of LayerNorm: nd = rho (vd_c - n mean(n vd_c))
 __device__ inline void ln_jvp_a(const float vd[4], const float n[4], float rho, float nd[4]) {
     const float md = red_q(vd[0] + vd[1] + vd[2] + vd[3]) * (1.0f / 16.0f);
@@ -383,9 +398,13 @@ template <typename T> struct FwdW {
         const T* pw = (const T*)d.con_w;  // [32][16]
         wp[0] = load_bfrag<T>(pw, 16, 1, 0, 0, q, m);
         wp[1] = load_bfrag<T>(pw, 16, 1, 16, 0, q, m);
+        float bmean = 0.f;      // the conv bias is centred over the 16 output channels (see ln_fwd_centered)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) bmean += d.conv_b[c];
+        bmean *= 1.0f / 16.0f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            bc[i] = d.conv_b[4 * q + i]; bp[i] = d.con_b[4 * q + i]; ls[i] = d.ls[4 * q + i];
+            bc[i] = d.conv_b[4 * q + i] - bmean; bp[i] = d.con_b[4 * q + i]; ls[i] = d.ls[4 * q + i];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 be[j][i] = d.exp_b[16 * j + 4 * q + i];
@@ -403,14 +422,28 @@ template <typename T> struct FwdW {
         }
     }
 };
-// conv weights [tap][ic][oc] as A-operand fragments of the transposed product (row = oc, k = ic), one per lane
+// conv weights [tap][ic][oc] as A-operand fragments of the transposed product (row = oc, k = ic), one per lane --
+// CENTRED over the output channels: W'[tap][ic][oc] = W - mean_oc W.  The LayerNorm that follows the conv is invariant
+// to a per-pixel shift of all 16 channels, so LN(conv_W(x) + b) == LN(conv_W'(x) + b') with b' = b - mean(b), and the
+// centred form needs no mean in the per-pixel chain (ln_fwd_centered).  Everything derived from the stash (the
+// FiLM-folded weights and biases of RowW, the border-tile taps) is centred with it.  In bf16 storage W' is rounded to
+// bf16 again: the residual channel mean is of the order of one bf16 ulp of the conv output, like any other rounding
+// between the kernels of this path.  The reverse kernels take the gradient w.r.t. the ORIGINAL weights (the LayerNorm
+// backward output already sums to zero over the channels, so dL/dW = h2^T dc1 is unchanged).
 template <typename T>
 __device__ inline void stash_conv_w(T* wc0, const Dev& d, int q, int m, int lane) {
     typedef typename Frag<T>::type frag_t;
     const T* cw = (const T*)d.conv_w;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-        *reinterpret_cast<frag_t*>(wc0 + (t * 64 + lane) * 4) = load_bfrag<T>(cw + t * 256, 16, 1, 0, 0, q, m);
+    for (int t = 0; t < 9; ++t) {
+        float wv[4];
+        unfrag(load_bfrag<T>(cw + t * 256, 16, 1, 0, 0, q, m), wv);      // lane (q, m): W[tap][ic = 4q + i][oc = m]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wv[i] -= red_m(wv[i]) * (1.0f / 16.0f);
+        frag_t f;
+        make_frag(f, wv[0], wv[1], wv[2], wv[3]);
+        *reinterpret_cast<frag_t*>(wc0 + (t * 64 + lane) * 4) = f;
+    }
 }
 
 // The row-r dependent part: FiLM folded into the conv.
@@ -549,12 +582,12 @@ __device__ inline void chain_row(const T* tile, const T* tiled, const T* wc0, co
                 }
             }
     }
-    float v[4] = {acc[0], acc[1], acc[2], acc[3]}, mean;
-    ln_fwd_a(v, o.n1, mean, o.rho1);
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    ln_fwd_centered(v, o.n1, o.rho1);
     make_frag(o.n1f, o.n1[0], o.n1[1], o.n1[2], o.n1[3]);
     if constexpr (JVP) {
         float vd[4] = {accd[0], accd[1], accd[2], accd[3]}, nd[4];
-        ln_jvp_a(vd, o.n1, o.rho1, nd);
+        ln_jvp_centered(vd, o.n1, o.rho1, nd);
         make_frag(o.n1df, nd[0], nd[1], nd[2], nd[3]);
     }
 #pragma unroll
@@ -603,7 +636,7 @@ __device__ inline bool tile_on_border(int s, int y0, int x0) { return y0 == 0 ||
 
 // MODE 0: GRN statistics; MODE 1: apply GRN, contract, layer-scale, residual.
 template <typename T, bool JVP, int MODE>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, (sizeof(T) == 2 && JVP && MODE == 0) ? 3 : 1)   // bf16 tangent statistics: <= 168 registers
 cnx_fwd_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Frag<T>::type frag_t;

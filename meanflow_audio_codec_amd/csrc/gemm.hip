@@ -422,13 +422,17 @@ __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t by
 }
 constexpr uint32_t NS_OOB = 0xFFFFFF00u;
 
-template <int MT>
+// NSUB = 64-column tiles a workgroup handles per loop iteration.  With NSUB = 2 (MT <= 3: the accumulators of two tiles
+// fit under 256 registers) twice the bytes are in flight per workgroup and every barrier / wait is paid once per 128
+// columns: the loop is bound by the latency of the prefetched B tile, not by bandwidth (one tile in flight per workgroup
+// and two workgroups per CU are ~32 KB per CU; at ~2 us of loaded HBM latency that is ~4 TB/s chip-wide).
+template <int MT, int NSUB>
 __global__ void __launch_bounds__(GT)
 gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     typedef u16 T;
     typedef Frag<T>::type frag_t;
-    __shared__ __attribute__((aligned(16))) T Bs[NS_K * NS_LDR];
-    __shared__ __attribute__((aligned(16))) float bias_s[NS_BN];
+    __shared__ __attribute__((aligned(16))) T Bs[NSUB][NS_K * NS_LDR];
+    __shared__ __attribute__((aligned(16))) float bias_s[NSUB][NS_BN];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, r = lane & 15;
@@ -465,13 +469,15 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
         boff[p] = (uint32_t)((k * g.ldb + c8) * 2);
         lds_off[p] = k * NS_LDR + c8;
     }
-    u32x4 rb[4];
-    auto load_b = [&](int64_t tile) {
-        const int64_t n0 = tile * NS_BN;
+    u32x4 rb[NSUB][4];
+    // tiles past the end are clamped to the last one for LOADS (finite data, results never stored: see colok below)
+    auto load_b = [&](int sub, int64_t tile) {
+        const int64_t tl = tile < ntiles ? tile : ntiles - 1;
+        const int64_t n0 = tl * NS_BN;
         // columns >= N of rows < K-1 alias the next row (finite weights, results never stored); the last row is clipped
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(B + n0, (uint32_t)(((NS_K - 1) * g.ldb + (N - n0)) * 2));
 #pragma unroll
-        for (int p = 0; p < 4; ++p) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[p], 0, 0);
+        for (int p = 0; p < 4; ++p) rb[sub][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[p], 0, 0);
     };
 
     // The products are issued TRANSPOSED (C^T tile = B^T A^T: the weight tile is the MFMA A operand, the resident
@@ -481,52 +487,73 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     const int lr = r, lc = 16 * q;
     const bool has_alpha = g.alpha != 1.0f;
     const __amdgpu_buffer_rsrc_t rs_bias = make_rsrc(g.bias, g.bias ? (uint32_t)(N * 4) : 0u);
-    // Loop shape: the B tile of iteration t+1 is requested at the top of iteration t and committed to LDS at its
+    // Loop shape: the B tiles of iteration t+1 are requested at the top of iteration t and committed to LDS at its
     // bottom, so the wait sits in the same iteration as the request and only has to skip the VMEM instructions
     // issued in between (the epilogue stores) -- it never drains them.  The bias loads go first: vmcnt is in-order,
     // waiting for anything younger than the B request would wait for the B tile as well.
-    int64_t tile = blockIdx.x;
-    if (tile < ntiles) {
-        load_b(tile);
+    // Iteration `it` of a workgroup covers tiles NSUB * it .. NSUB * it + NSUB - 1.
+    const int64_t niter = (ntiles + NSUB - 1) / NSUB;
+    int64_t it = blockIdx.x;
+    if (it < niter) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs + lds_off[p]) = rb[p];
+        for (int sub = 0; sub < NSUB; ++sub) load_b(sub, NSUB * it + sub);
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs[sub] + lds_off[p]) = rb[sub][p];
     }
     __syncthreads();
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int64_t col0 = tile * NS_BN + lc;
-        const bool colok = col0 < N;
-        // the tile's 64 bias values: 16 lanes x 16 bytes, parked in LDS after the MFMAs (no registers held across them)
-        const u32x4 bias_v = __builtin_amdgcn_raw_buffer_load_b128(
-            rs_bias, (threadIdx.x < 16 && tile * NS_BN + 4 * threadIdx.x < N) ? (uint32_t)((tile * NS_BN + 4 * threadIdx.x) * 4) : NS_OOB, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);   // keep it OLDER than the B request below (in-order vmcnt)
-        // prefetch (past the end: re-request this tile, never committed -- keeps the instruction unconditional)
+    for (; it < niter; it += gridDim.x) {
+        // the tiles' 64 bias values each: 16 lanes x 16 bytes, parked in LDS after the MFMAs (no registers held across them)
+        u32x4 bias_v[NSUB];
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int64_t tile = NSUB * it + sub;
+            bias_v[sub] = __builtin_amdgcn_raw_buffer_load_b128(
+                rs_bias, (threadIdx.x < 16 && tile * NS_BN + 4 * threadIdx.x < N) ? (uint32_t)((tile * NS_BN + 4 * threadIdx.x) * 4) : NS_OOB, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep them OLDER than the B requests below (in-order vmcnt)
+        // prefetch (past the end: re-request this iteration's tiles, never committed -- keeps the instructions unconditional)
         {
-            const int64_t nt = tile + gridDim.x < ntiles ? tile + gridDim.x : tile;
-            load_b(nt);
+            const int64_t nit = it + gridDim.x < niter ? it + gridDim.x : it;
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) load_b(sub, NSUB * nit + sub);
         }
 
-        f32x4 acc[MT][4];
+        f32x4 acc[NSUB][MT][4];
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < NS_KS; ++c) {
-            frag_t bf[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // LDS transpose read: lane 4q'+p of group q supplies k-row 4q+q', columns 16p + 4j .. +3
-                const T* bp = Bs + (16 * c + 4 * q + (r >> 2)) * NS_LDR + 16 * (r & 3) + 4 * j;
-                bf[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
-            }
+        for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mma16(acc[i][j], bf[j], af[i][c]);
+                for (int j = 0; j < 4; ++j) acc[sub][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+            for (int c = 0; c < NS_KS; ++c) {
+                frag_t bf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // LDS transpose read: lane 4q'+p of group q supplies k-row 4q+q', columns 16p + 4j .. +3
+                    const T* bp = Bs[sub] + (16 * c + 4 * q + (r >> 2)) * NS_LDR + 16 * (r & 3) + 4 * j;
+                    bf[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma16(acc[sub][i][j], bf[j], af[i][c]);
+            }
+        if (threadIdx.x < 16) {
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) *reinterpret_cast<u32x4*>(bias_s[sub] + 4 * threadIdx.x) = bias_v[sub];
         }
-        if (threadIdx.x < 16) *reinterpret_cast<u32x4*>(bias_s + 4 * threadIdx.x) = bias_v;
-        __syncthreads();   // B tile consumed: the next iteration may overwrite it while slower waves are in the epilogue
+        __syncthreads();   // B tiles consumed: the next iteration may overwrite them while slower waves are in the epilogue
 
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
+        const int64_t tile = NSUB * it + sub;
+        const int64_t col0 = tile * NS_BN + lc;
+        const bool colok = tile < ntiles && col0 < N;
         // epilogue: one lane = 16 consecutive columns of one row, straight from the accumulators
         uint32_t npr[8];       // the normalised primal of a (primal, tangent) tile pair, as stored (bf16 pairs)
         float rho_pr = 0.f;
@@ -538,7 +565,7 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[i][j][e];
+                for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[sub][i][j][e];
             // wave-uniform geometry of this 16-row tile (a wave without an i-th tile gets an empty resource)
             const int64_t row0 = 16 * (int64_t)(mt[i] < 0 ? 0 : mt[i]);
             const int64_t rows_valid = mt[i] < 0 ? 0 : (g.M - row0 < 16 ? g.M - row0 : 16);
@@ -547,7 +574,7 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
                 const bool hb = lr < rows_bias;
 #pragma unroll
                 for (int k4 = 0; k4 < 4; ++k4) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + lc + 4 * k4);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s[sub] + lc + 4 * k4);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[4 * k4 + k] += hb ? b4[k] : 0.f;
                 }
@@ -610,9 +637,12 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
                 __builtin_amdgcn_raw_buffer_store_b128(t, rs_c, coff + 16 * h, 0, 0);
             }
         }
-        // commit the prefetched B tile (every wave left the MFMA loop at the barrier above)
+      }
+        // commit the prefetched B tiles (every wave left the MFMA loop at the barrier above)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs + lds_off[p]) = rb[p];
+        for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs[sub] + lds_off[p]) = rb[sub][p];
         __syncthreads();
     }
 }
@@ -784,6 +814,10 @@ inline bool ns_disabled() {
     static const bool off = [] { const char* e = getenv("MFC_GEMM_NSTREAM"); return e && e[0] == '0'; }();
     return off;
 }
+inline bool ns_two_tiles() {      // MFC_GEMM_NS_SUB=1: one tile per iteration (A/B switch)
+    static const bool on = [] { const char* e = getenv("MFC_GEMM_NS_SUB"); return !(e && e[0] == '1'); }();
+    return on;
+}
 inline int64_t ns_max_blocks() {
     static const int64_t n = [] { const char* e = getenv("MFC_GEMM_NS_BLOCKS"); const long v = e ? atol(e) : 0; return (int64_t)(v > 0 ? v : 512); }();
     return n;
@@ -895,12 +929,24 @@ int gemm_impl(int dtype, int flags, int64_t M, int64_t N, int64_t K, const void*
         const int mt = ns_make_plan(M, bias_rows, ln, ln_tan, plan);
         if (mt > 0) {
             const int64_t ntiles = ceil_div64(N, NS_BN);
-            int64_t grid = ntiles < ns_max_blocks() ? ntiles : ns_max_blocks();
-            switch (mt) {
-                case 1: hipLaunchKernelGGL((gemm_nstream_kernel<1>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles); break;
-                case 2: hipLaunchKernelGGL((gemm_nstream_kernel<2>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles); break;
-                case 3: hipLaunchKernelGGL((gemm_nstream_kernel<3>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles); break;
-                default: hipLaunchKernelGGL((gemm_nstream_kernel<4>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles); break;
+            // two tiles per iteration when the accumulators fit (MT <= 3) and there is enough work to fill the grid twice
+            const int nsub = (mt <= 3 && ns_two_tiles() && ntiles >= 4 * ns_max_blocks()) ? 2 : 1;
+            const int64_t niter = ceil_div64(ntiles, nsub);
+            int64_t grid = niter < ns_max_blocks() ? niter : ns_max_blocks();
+            const dim3 gd((unsigned)grid), bd(GT);
+            if (nsub == 2) {
+                switch (mt) {
+                    case 1: hipLaunchKernelGGL((gemm_nstream_kernel<1, 2>), gd, bd, 0, st, g, plan, ntiles); break;
+                    case 2: hipLaunchKernelGGL((gemm_nstream_kernel<2, 2>), gd, bd, 0, st, g, plan, ntiles); break;
+                    default: hipLaunchKernelGGL((gemm_nstream_kernel<3, 2>), gd, bd, 0, st, g, plan, ntiles); break;
+                }
+            } else {
+                switch (mt) {
+                    case 1: hipLaunchKernelGGL((gemm_nstream_kernel<1, 1>), gd, bd, 0, st, g, plan, ntiles); break;
+                    case 2: hipLaunchKernelGGL((gemm_nstream_kernel<2, 1>), gd, bd, 0, st, g, plan, ntiles); break;
+                    case 3: hipLaunchKernelGGL((gemm_nstream_kernel<3, 1>), gd, bd, 0, st, g, plan, ntiles); break;
+                    default: hipLaunchKernelGGL((gemm_nstream_kernel<4, 1>), gd, bd, 0, st, g, plan, ntiles); break;
+                }
             }
             return mfc_launch_status();
         }
