@@ -406,6 +406,7 @@ gemm_kernel(GemmArgs g) {
 // the tangent of the fused LayerNorm in the same epilogue.
 // ---------------------------------------------------------------------------
 constexpr int NS_BN = 64, NS_K = 128, NS_KS = NS_K / 16, NS_LDR = 80, NS_MAXT = 4;
+constexpr int NS_CROW = 272;   // bytes per row of the NSUB == 2 output staging image (256 + 16: conflict-free b128 writes)
 struct NsPlan {
     // per wave: up to 4 16-row tiles of C, processed in order; kind 0 = plain, 1 = LN16 primal,
     // 2 = LN16 tangent of the entry before it
@@ -433,6 +434,8 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     typedef Frag<T>::type frag_t;
     __shared__ __attribute__((aligned(16))) T Bs[NSUB][NS_K * NS_LDR];
     __shared__ __attribute__((aligned(16))) float bias_s[NSUB][NS_BN];
+    // NSUB == 2: per wave [16 rows][256 B + 16 B pad] staging image of the output rows (see the epilogue)
+    __shared__ __attribute__((aligned(16))) unsigned char cstage[NSUB == 2 ? 4 * 16 * NS_CROW : 16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, r = lane & 15;
@@ -549,95 +552,119 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
         }
         __syncthreads();   // B tiles consumed: the next iteration may overwrite them while slower waves are in the epilogue
 
+        // epilogue: one lane = 16 consecutive columns of one row per 64-column tile, straight from the accumulators.
+        // NSUB == 2: the two tiles' 32-byte pieces of a row are gathered in a wave-private LDS image [16 rows][256 B] and
+        // leave as four 256-byte row segments per store instruction (16 lanes x 16 B per row) instead of sixteen 64-byte
+        // ones -- the access shape that lifted the AdamW epilogue from 5.2 to 5.9 TB/s.
+        uint32_t npr[NSUB][8];       // the normalised primal of a (primal, tangent) tile pair, as stored (bf16 pairs)
+        float rho_pr[NSUB];
 #pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub) {
-        const int64_t tile = NSUB * it + sub;
-        const int64_t col0 = tile * NS_BN + lc;
-        const bool colok = tile < ntiles && col0 < N;
-        // epilogue: one lane = 16 consecutive columns of one row, straight from the accumulators
-        uint32_t npr[8];       // the normalised primal of a (primal, tangent) tile pair, as stored (bf16 pairs)
-        float rho_pr = 0.f;
+        for (int sub = 0; sub < NSUB; ++sub) {
+            rho_pr[sub] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) npr[k] = 0u;
+            for (int k = 0; k < 8; ++k) npr[sub][k] = 0u;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            float v[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[sub][i][j][e];
             // wave-uniform geometry of this 16-row tile (a wave without an i-th tile gets an empty resource)
             const int64_t row0 = 16 * (int64_t)(mt[i] < 0 ? 0 : mt[i]);
             const int64_t rows_valid = mt[i] < 0 ? 0 : (g.M - row0 < 16 ? g.M - row0 : 16);
             const int64_t rows_bias = g.bias_rows - row0;      // rows [0, rows_bias) of the tile take the bias
-            if (rows_bias > 0) {
-                const bool hb = lr < rows_bias;
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s[sub] + lc + 4 * k4);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[4 * k4 + k] += hb ? b4[k] : 0.f;
-                }
-            }
-            if (has_alpha) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] *= g.alpha;
-            }
-            if (kind[i] == 1) {
-                rho_pr = ln16_lane(v);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) npr[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
-            } else if (kind[i] == 2) {
-                float n[16];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    n[2 * k] = __builtin_bit_cast(float, (uint32_t)(npr[k] << 16));
-                    n[2 * k + 1] = __builtin_bit_cast(float, (uint32_t)(npr[k] & 0xffff0000u));
-                }
-                ln16_tangent_lane(v, n, rho_pr);
-            }
-            {   // 1/sigma of the LN16 primal rows (empty resource otherwise)
-                const uint32_t bytes = kind[i] == 1 ? (uint32_t)(rows_valid * (N >> 4) * 4) : 0u;
-                const __amdgpu_buffer_rsrc_t rs = make_rsrc(g.ln_rstd ? g.ln_rstd + row0 * (N >> 4) : nullptr, g.ln_rstd ? bytes : 0u);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, rho_pr), rs,
-                                                      colok ? (uint32_t)((lr * (N >> 4) + (col0 >> 4)) * 4) : NS_OOB, 0, 0);
-            }
             const uint32_t cbytes = rows_valid > 0 ? (uint32_t)(((rows_valid - 1) * g.ldc + N) * 2) : 0u;
-            const uint32_t coff = colok ? (uint32_t)((lr * g.ldc + col0) * 2) : NS_OOB;
-            if (g.R) {
-                const uint32_t rbytes = rows_valid > 0 ? (uint32_t)(((rows_valid - 1) * g.ldr + N) * 2) : 0u;
-                const __amdgpu_buffer_rsrc_t rs = make_rsrc((const T*)g.R + row0 * g.ldr, rbytes);
-                const uint32_t roff = colok ? (uint32_t)((lr * g.ldr + col0) * 2) : NS_OOB;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, roff + 16 * h, 0, 0);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        v[8 * h + 2 * k] += g.beta * __builtin_bit_cast(float, (uint32_t)(t[k] << 16));
-                        v[8 * h + 2 * k + 1] += g.beta * __builtin_bit_cast(float, (uint32_t)(t[k] & 0xffff0000u));
-                    }
-                }
-            }
             const __amdgpu_buffer_rsrc_t rs_c = make_rsrc((T*)g.C + row0 * g.ldc, cbytes);
-            if (g.accum) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_c, coff + 16 * h, 0, 0);
+            for (int sub = 0; sub < NSUB; ++sub) {
+                const int64_t tile = NSUB * it + sub;
+                const int64_t col0 = tile * NS_BN + lc;
+                const bool colok = tile < ntiles && col0 < N;
+                float v[16];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        v[8 * h + 2 * k] += __builtin_bit_cast(float, (uint32_t)(t[k] << 16));
-                        v[8 * h + 2 * k + 1] += __builtin_bit_cast(float, (uint32_t)(t[k] & 0xffff0000u));
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[sub][i][j][e];
+                if (rows_bias > 0) {
+                    const bool hb = lr < rows_bias;
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s[sub] + lc + 4 * k4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[4 * k4 + k] += hb ? b4[k] : 0.f;
                     }
                 }
-            }
+                if (has_alpha) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const u32x4 t = {pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
-                                 pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
-                __builtin_amdgcn_raw_buffer_store_b128(t, rs_c, coff + 16 * h, 0, 0);
+                    for (int k = 0; k < 16; ++k) v[k] *= g.alpha;
+                }
+                if (kind[i] == 1) {
+                    rho_pr[sub] = ln16_lane(v);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) npr[sub][k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+                } else if (kind[i] == 2) {
+                    float n[16];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        n[2 * k] = __builtin_bit_cast(float, (uint32_t)(npr[sub][k] << 16));
+                        n[2 * k + 1] = __builtin_bit_cast(float, (uint32_t)(npr[sub][k] & 0xffff0000u));
+                    }
+                    ln16_tangent_lane(v, n, rho_pr[sub]);
+                }
+                {   // 1/sigma of the LN16 primal rows (empty resource otherwise)
+                    const uint32_t bytes = kind[i] == 1 ? (uint32_t)(rows_valid * (N >> 4) * 4) : 0u;
+                    const __amdgpu_buffer_rsrc_t rs = make_rsrc(g.ln_rstd ? g.ln_rstd + row0 * (N >> 4) : nullptr, g.ln_rstd ? bytes : 0u);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, rho_pr[sub]), rs,
+                                                          colok ? (uint32_t)((lr * (N >> 4) + (col0 >> 4)) * 4) : NS_OOB, 0, 0);
+                }
+                const uint32_t coff = colok ? (uint32_t)((lr * g.ldc + col0) * 2) : NS_OOB;
+                if (g.R) {
+                    const uint32_t rbytes = rows_valid > 0 ? (uint32_t)(((rows_valid - 1) * g.ldr + N) * 2) : 0u;
+                    const __amdgpu_buffer_rsrc_t rs = make_rsrc((const T*)g.R + row0 * g.ldr, rbytes);
+                    const uint32_t roff = colok ? (uint32_t)((lr * g.ldr + col0) * 2) : NS_OOB;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, roff + 16 * h, 0, 0);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            v[8 * h + 2 * k] += g.beta * __builtin_bit_cast(float, (uint32_t)(t[k] << 16));
+                            v[8 * h + 2 * k + 1] += g.beta * __builtin_bit_cast(float, (uint32_t)(t[k] & 0xffff0000u));
+                        }
+                    }
+                }
+                if (g.accum) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_c, coff + 16 * h, 0, 0);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            v[8 * h + 2 * k] += __builtin_bit_cast(float, (uint32_t)(t[k] << 16));
+                            v[8 * h + 2 * k + 1] += __builtin_bit_cast(float, (uint32_t)(t[k] & 0xffff0000u));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x4 t = {pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                                     pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+                    if constexpr (NSUB == 2)
+                        *reinterpret_cast<u32x4*>(cstage + (wave * 16 + lr) * NS_CROW + sub * 128 + 2 * lc + 16 * h) = t;
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(t, rs_c, coff + 16 * h, 0, 0);
+                }
+            }
+            if constexpr (NSUB == 2) {
+                // LDS operations of one wave execute in order: only the compiler must keep the reads below the writes
+                asm volatile("" ::: "memory");
+                const int64_t colb = NSUB * it * NS_BN;           // first column of the 128-column pair
+                const int chunk = lane & 15;                       // 16-byte chunk (8 columns) of the 256-byte row segment
+                const bool cok = colb + 8 * chunk < N;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int rr = 4 * h + (lane >> 4);
+                    const u32x4 t = *reinterpret_cast<const u32x4*>(cstage + (wave * 16 + rr) * NS_CROW + 16 * chunk);
+                    __builtin_amdgcn_raw_buffer_store_b128(t, rs_c, cok ? (uint32_t)((rr * g.ldc + colb + 8 * chunk) * 2) : NS_OOB, 0, 0);
+                }
+                asm volatile("" ::: "memory");
             }
         }
-      }
         // commit the prefetched B tiles (every wave left the MFMA loop at the barrier above)
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub)

@@ -256,6 +256,15 @@ mdct512_inv_kernel(const float* __restrict__ X, int64_t nf, int hop, int hop_shi
     const int lead = (2 * N + hop - 1) / hop - 1;
     const float scale = 2.0f / (float)N;
     f32x4 pre[INV_V];
+    // first 16-row block of segment gg (also called one segment ahead, from the last iteration of the previous one)
+    auto fetch_first = [&](int64_t gg) {
+        const int64_t bb = gg / spc;
+        const int64_t s0 = (gg - bb * spc) * seg_frames;
+        const int64_t e0 = (s0 + seg_frames < nf) ? s0 + seg_frames : nf;
+        const int64_t cb = s0 > lead ? s0 - lead : 0;
+        inv_fetch(pre, X + (bb * nf + cb) * (int64_t)N, (int)((e0 - cb) < F ? (e0 - cb) : F), tid);
+    };
+    if ((int64_t)blockIdx.x < n_segs) fetch_first(blockIdx.x);
 
     for (int64_t g = blockIdx.x; g < n_segs; g += gridDim.x) {
         const int64_t b = g / spc;
@@ -271,10 +280,6 @@ mdct512_inv_kernel(const float* __restrict__ X, int64_t nf, int hop, int hop_shi
         float* carry_out = l.extra + CL;
         __syncthreads();
         for (int q = tid; q < CL; q += NT) carry_in[q] = 0.f;
-        {
-            const int n0 = (int)((fe - c_begin) < F ? (fe - c_begin) : F);
-            inv_fetch(pre, Xb + c_begin * N, n0, tid);
-        }
         for (int64_t c0 = c_begin; c0 < fe; c0 += F) {
             const int nfr = (int)((fe - c0) < F ? (fe - c0) : F);
             __syncthreads();                   // previous iteration's overlap-add has finished reading U
@@ -297,6 +302,8 @@ mdct512_inv_kernel(const float* __restrict__ X, int64_t nf, int hop, int hop_shi
             if (c0 + F < fe) {
                 const int nn = (int)((fe - c0 - F) < F ? (fe - c0 - F) : F);
                 inv_fetch(pre, Xb + (c0 + F) * N, nn, tid);
+            } else if (g + gridDim.x < n_segs) {
+                fetch_first(g + gridDim.x);       // the next segment's first block, in flight across the segment change
             }
             __syncthreads();
             fft256(z, l.wjt, l.ex, f, j);

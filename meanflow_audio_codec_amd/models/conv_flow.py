@@ -43,13 +43,12 @@ class ConditionalConvFlow:
                  latent_input_dim: int | None = None, dtype: torch.dtype = torch.float32):
         if condition_dimension % 2:
             raise ValueError(f"condition_dimension must be even, got {condition_dimension}")
-        if not use_grn:
-            raise NotImplementedError("use_grn=False is not implemented in the HIP path")
         self.noise_dimension = noise_dimension
         self.condition_dimension = condition_dimension
         self.num_blocks = num_blocks
         self.latent_dimension = latent_dimension
         self.num_latent_tokens = num_latent_tokens
+        self.use_grn = bool(use_grn)               # models/conv_flow.py:91-92: False skips GlobalResponseNormalization
         self.spatial_size = int(math.sqrt(noise_dimension))            # conv_flow.py:138
         self.channels = min(16, condition_dimension // 4)              # conv_flow.py:139
         if self.channels != 16:
@@ -75,8 +74,9 @@ class ConditionalConvFlow:
             cb = f"{b}/conv_block"
             sh[f"{cb}/Conv_0/kernel"] = (3, 3, C, C); sh[f"{cb}/Conv_0/bias"] = (C,)
             sh[f"{cb}/Conv_1/kernel"] = (1, 1, C, 2 * C); sh[f"{cb}/Conv_1/bias"] = (2 * C,)
-            sh[f"{cb}/GlobalResponseNormalization_0/gamma"] = (2 * C,)
-            sh[f"{cb}/GlobalResponseNormalization_0/beta"] = (2 * C,)
+            if self.use_grn:
+                sh[f"{cb}/GlobalResponseNormalization_0/gamma"] = (2 * C,)
+                sh[f"{cb}/GlobalResponseNormalization_0/beta"] = (2 * C,)
             sh[f"{cb}/Conv_2/kernel"] = (1, 1, 2 * C, C); sh[f"{cb}/Conv_2/bias"] = (C,)
             sh[f"{cb}/layer_scale_gamma"] = (C,)
             sh[f"{b}/output_proj1/kernel"] = (S, BOTTLENECK); sh[f"{b}/output_proj1/bias"] = (BOTTLENECK,)
@@ -99,17 +99,30 @@ class ConditionalConvFlow:
         return torch.float32 if name.endswith(small) else self.dtype
 
     # ------------------------------------------------------------------ helpers
-    def _cnx_w(self, w: dict, i: int) -> dict:
+    def _cnx_w(self, w: dict, i: int, grads: bool = False) -> dict:
         cb = f"blocks_{i}/conv_block"
+        dev = w[f"{cb}/Conv_0/bias"].device
+        if self.use_grn:
+            gam, bet = w[f"{cb}/GlobalResponseNormalization_0/gamma"], w[f"{cb}/GlobalResponseNormalization_0/beta"]
+        elif grads:
+            # use_grn=False: the kernels still emit d gamma / d beta; they land in scratch nobody reads
+            gam, bet = self._buf(("nogrn_dg",), (32,), torch.float32, dev), self._buf(("nogrn_db",), (32,), torch.float32, dev)
+        else:
+            # use_grn=False: y = g * (gamma + q) + beta with gamma = 1, beta = 0, q = 0 is the identity on g
+            gam = self._ws.get(("nogrn_one", dev))
+            if gam is None:
+                gam = self._ws[("nogrn_one", dev)] = torch.ones(32, dtype=torch.float32, device=dev)
+            bet = self._ws.get(("nogrn_zero", dev))
+            if bet is None:
+                bet = self._ws[("nogrn_zero", dev)] = torch.zeros(32, dtype=torch.float32, device=dev)
         return {"conv_w": w[f"{cb}/Conv_0/kernel"], "conv_b": w[f"{cb}/Conv_0/bias"],
                 "exp_w": w[f"{cb}/Conv_1/kernel"], "exp_b": w[f"{cb}/Conv_1/bias"],
-                "grn_gamma": w[f"{cb}/GlobalResponseNormalization_0/gamma"],
-                "grn_beta": w[f"{cb}/GlobalResponseNormalization_0/beta"],
+                "grn_gamma": gam, "grn_beta": bet,
                 "con_w": w[f"{cb}/Conv_2/kernel"], "con_b": w[f"{cb}/Conv_2/bias"],
                 "ls": w[f"{cb}/layer_scale_gamma"]}
 
     def _cnx_g(self, g: dict, i: int) -> dict:
-        return self._cnx_w(g, i)
+        return self._cnx_w(g, i, grads=True)
 
     def _buf(self, key, shape, dtype, device):
         t = self._ws.get(key)
@@ -212,10 +225,12 @@ class ConditionalConvFlow:
             if n_tan:
                 scd, shd = cp[R:, :16].contiguous(), cp[R:, 16:].contiguous()
                 _, _, G, q = ops.cnx_forward(H0[:n_tan], sc[:n_tan], sh[:n_tan], cw, s, h0dot=H0[R:],
-                                             scaledot=scd, shiftdot=shd, out=O[:n_tan], outdot=O[R:])
+                                             scaledot=scd, shiftdot=shd, out=O[:n_tan], outdot=O[R:],
+                                             use_grn=self.use_grn)
                 Gs.append(G); qs.append(q)
             if R > n_tan:
-                _, _, G, q = ops.cnx_forward(H0[n_tan:R], sc[n_tan:], sh[n_tan:], cw, s, out=O[n_tan:R])
+                _, _, G, q = ops.cnx_forward(H0[n_tan:R], sc[n_tan:], sh[n_tan:], cw, s, out=O[n_tan:R],
+                                             use_grn=self.use_grn)
                 Gs.append(G); qs.append(q)
             a2 = dense(O, w[f"{b}/output_proj1/kernel"], w[f"{b}/output_proj1/bias"], bias_rows=R)
             g2 = ops.gelu_fwd(a2, act_rows=R)
@@ -273,7 +288,7 @@ class ConditionalConvFlow:
             for t_ in cg.values():
                 t_.zero_()
             _, dsc, dsh = ops.cnx_backward(H0, ctx.sc[i], ctx.sh[i], self._cnx_w(w, i), s, ctx.G[i], ctx.q[i], dO, cg,
-                                           dh0=dH0, scratch=dC1, rho0=ctx.rho[i])
+                                           dh0=dH0, scratch=dC1, rho0=ctx.rho[i], use_grn=self.use_grn)
             dcp = torch.cat([dsc, dsh], 1).contiguous()
             dense_dw(ctx.cond, dcp, out=grads[f"{b}/conditioning_layer/kernel"])
             ops.colsum(dcp, out=grads[f"{b}/conditioning_layer/bias"])

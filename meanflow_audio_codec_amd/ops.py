@@ -147,7 +147,7 @@ def cnx_workspace(R: int, s: int, device) -> torch.Tensor:
 
 
 def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, shiftdot=None, out=None,
-                outdot=None):
+                outdot=None, use_grn: bool = True):
     """o = ConvNeXtBlock(FiLM(h1)) on [R, s, s, 16] where ``h0`` holds h1 = LN(h0) and ``h0dot`` the
     tangent of that LayerNorm (see ln16 / ln16_jvp, or the MFC_GEMM_LN16 / LN16T epilogue);
     returns (o, odot, G, q).  Runs mfc_cnx_stats -> mfc_grn_finalize -> mfc_cnx_apply."""
@@ -170,11 +170,18 @@ def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, sh
     G = torch.empty((R, 32), dtype=torch.float32, device=dev)
     q = torch.empty_like(G)
     qd = torch.empty_like(G) if jvp else None
-    _lib.check(L.mfc_cnx_stats(dt, R, s, h0.data_ptr(), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
-                               _lib.ptr(scaledot), _lib.ptr(shiftdot), ctypes.byref(ps), S[0].data_ptr(),
-                               S[1].data_ptr() if jvp else None, ws.data_ptr(), st), "mfc_cnx_stats")
-    _lib.check(L.mfc_grn_finalize(R, S[0].data_ptr(), S[1].data_ptr() if jvp else None, G.data_ptr(),
-                                  q.data_ptr(), _lib.ptr(qd), st), "mfc_grn_finalize")
+    if use_grn:
+        _lib.check(L.mfc_cnx_stats(dt, R, s, h0.data_ptr(), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
+                                   _lib.ptr(scaledot), _lib.ptr(shiftdot), ctypes.byref(ps), S[0].data_ptr(),
+                                   S[1].data_ptr() if jvp else None, ws.data_ptr(), st), "mfc_cnx_stats")
+        _lib.check(L.mfc_grn_finalize(R, S[0].data_ptr(), S[1].data_ptr() if jvp else None, G.data_ptr(),
+                                      q.data_ptr(), _lib.ptr(qd), st), "mfc_grn_finalize")
+    else:
+        # no GlobalResponseNormalization (conv_flow.py:91-92): the caller passes gamma = 1, beta = 0; with q = qdot = 0 the
+        # apply pass computes y = g, and no statistics pass is needed
+        G.zero_(); q.zero_()
+        if jvp:
+            qd.zero_()
     o = out if out is not None else torch.empty_like(h0)
     od = (outdot if outdot is not None else torch.empty_like(h0)) if jvp else None
     _lib.check(L.mfc_cnx_apply(dt, R, s, h0.data_ptr(), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
@@ -183,7 +190,8 @@ def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, sh
     return o, od, G, q
 
 
-def cnx_backward(h0, scale, shift, w: dict, s: int, G, q, dout, grads: dict, dh0=None, scratch=None, rho0=None):
+def cnx_backward(h0, scale, shift, w: dict, s: int, G, q, dout, grads: dict, dh0=None, scratch=None, rho0=None,
+                 use_grn: bool = True):
     """Backward of cnx_forward's primal (``h0`` = h1 = LN(h0), ``rho0`` its 1/sigma): returns
     (dh0, dscale, dshift) with dh0 the gradient w.r.t. the RAW h0 (LayerNorm backward included);
     accumulates (+=) the small-parameter gradients into the fp32 tensors of ``grads``."""
@@ -202,11 +210,14 @@ def cnx_backward(h0, scale, shift, w: dict, s: int, G, q, dout, grads: dict, dh0
     dq = torch.empty((R, 32), dtype=torch.float32, device=dev)
     kG = torch.empty_like(dq)
     ws = cnx_workspace(R, s, dev)
-    _lib.check(L.mfc_cnx_bwd_stats(dt, R, s, h0.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctypes.byref(ps),
-                                   q.data_ptr(), dout.data_ptr(), dq.data_ptr(), ws.data_ptr(), st),
-               "mfc_cnx_bwd_stats")
-    _lib.check(L.mfc_grn_bwd_finalize(R, G.data_ptr(), dq.data_ptr(), kG.data_ptr(),
-                                      grads["grn_gamma"].data_ptr(), st), "mfc_grn_bwd_finalize")
+    if use_grn:
+        _lib.check(L.mfc_cnx_bwd_stats(dt, R, s, h0.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctypes.byref(ps),
+                                       q.data_ptr(), dout.data_ptr(), dq.data_ptr(), ws.data_ptr(), st),
+                   "mfc_cnx_bwd_stats")
+        _lib.check(L.mfc_grn_bwd_finalize(R, G.data_ptr(), dq.data_ptr(), kG.data_ptr(),
+                                          grads["grn_gamma"].data_ptr(), st), "mfc_grn_bwd_finalize")
+    else:
+        kG.zero_()          # no GRN: d g = d y (gamma + q) + g kG with gamma = 1, q = 0, kG = 0
     dc1 = scratch if scratch is not None else torch.empty_like(h0)
     _lib.check(L.mfc_cnx_bwd_main(dt, R, s, h0.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctypes.byref(ps),
                                   q.data_ptr(), kG.data_ptr(), dout.data_ptr(), dc1.data_ptr(), ctypes.byref(gs),

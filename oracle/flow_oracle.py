@@ -99,7 +99,8 @@ def convnext_block(p, x):
     x = layer_norm(x)
     x = conv_nhwc(x, p["Conv_1"]["kernel"], p["Conv_1"]["bias"], 0)
     x = gelu(x)
-    x = grn(p["GlobalResponseNormalization_0"], x)
+    if "GlobalResponseNormalization_0" in p:          # use_grn (conv_flow.py:91-92); absent: no GRN parameters
+        x = grn(p["GlobalResponseNormalization_0"], x)
     x = conv_nhwc(x, p["Conv_2"]["kernel"], p["Conv_2"]["bias"], 0)
     x = x * p["layer_scale_gamma"]
     return x + res
@@ -144,7 +145,7 @@ def conv_flow_encode(params, x):
     return dense(p["dense2"], gelu(dense(p["dense1"], x)))
 
 
-def conv_flow_shapes(D, cond_dim, latent_in, num_blocks, latent_dim=None):
+def conv_flow_shapes(D, cond_dim, latent_in, num_blocks, latent_dim=None, use_grn=True):
     """name -> shape for ConditionalConvFlow."""
     s = int(math.sqrt(D))
     C = min(16, cond_dim // 4)
@@ -165,6 +166,9 @@ def conv_flow_shapes(D, cond_dim, latent_in, num_blocks, latent_dim=None):
             "output_proj1": {"kernel": (S, 128), "bias": (128,)},
             "output_proj2": {"kernel": (128, D), "bias": (D,)},
         }
+    if not use_grn:
+        for i in range(num_blocks):
+            del tree[f"blocks_{i}"]["conv_block"]["GlobalResponseNormalization_0"]
     if latent_in:
         tree["latent_proj"] = {"kernel": (latent_in, cond_dim), "bias": (cond_dim,)}
     if latent_dim:

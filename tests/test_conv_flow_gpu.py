@@ -303,3 +303,46 @@ def test_ci_shape_schedules_agree():
         ma, mb = snaps[0][k][0], snaps[1][k][0]
         scale = ma.abs().max().item()
         assert scale > 0 and (ma - mb).abs().max().item() <= 3e-2 * scale, (k, (ma - mb).abs().max().item(), scale)
+
+
+def test_use_grn_false_matches_oracle():
+    """ConvNeXtBlock(use_grn=False) (models/conv_flow.py:91-92): no GlobalResponseNormalization parameters, no
+    statistics pass -- forward, iMF loss and every gradient against the oracle without the GRN."""
+    from meanflow_audio_codec_amd.models import ConditionalConvFlow, TrainState, adamw
+    from meanflow_audio_codec_amd.trainers import ImprovedMeanFlowLoss, PRNGKey
+    model = ConditionalConvFlow(D, CD, NB, LAT, use_grn=False, dtype=torch.float32)
+    shapes = fo.conv_flow_shapes(D, CD, LAT, NB, latent_dim=LAT, use_grn=False)
+    flat64 = fo.flatten(fo.init_params(shapes, seed=3, special=False))
+    assert set(flat64) == set(model.param_shapes()) and not any("GlobalResponseNormalization" in k for k in flat64)
+    flat = {k: v.float().cuda().contiguous() for k, v in flat64.items()}
+    state = TrainState.create(apply_fn=model.apply, params=flat, tx=adamw(1e-3, 1e-2), model=model)
+    pq = fo.unflatten({k: state.work[k].double().cpu() for k in flat})
+    x, e, t, r = _draws(5, seed=8)
+    g = torch.Generator().manual_seed(2)
+    time = torch.rand(5, 2, generator=g)
+    lat = torch.randn(5, LAT, generator=g)
+    ref = fo.conv_flow_apply(pq, x.double(), time.double(), lat.double())
+    out = model.apply({"params": state.work}, x.cuda(), time.cuda(), lat.cuda())
+    assert _rel(out, ref) < 1e-4
+    loss_ref, g_ref, aux_ref = fo.imf_loss(fo.conv_flow_apply, fo.conv_flow_encode, pq, x.double(), e.double(),
+                                           t.double(), r.double())
+    loss, grads = ImprovedMeanFlowLoss().compute_loss(state, PRNGKey(0), x.cuda(), e=e.cuda(), t=t.cuda(), r=r.cuda())
+    assert abs(loss.item() - loss_ref.item()) < 2e-4 * max(1.0, abs(loss_ref.item()))
+    for k, gr in fo.flatten(g_ref).items():
+        scale = gr.abs().max().item()
+        if scale > 0:
+            assert ((grads[k].double().cpu() - gr).abs().max().item() / scale) < 2e-3, k
+
+
+def test_cfg_sampling_matches_oracle():
+    """evaluators/sampling.py:50-96 with classifier-free guidance (guidance_scale != 1: conditional and unconditional
+    velocity blended in both Heun stages) on the ConvNeXt flow, against the oracle's heun_sample."""
+    from meanflow_audio_codec_amd.evaluators.sampling import heun_integrate
+    model, state, pq = _make(torch.float32, seed=13, special=False)
+    g = torch.Generator().manual_seed(14)
+    x0 = torch.randn(4, D, generator=g)
+    lat = torch.randn(4, LAT, generator=g)
+    for gs, n_steps in ((2.0, 2), (0.5, 3), (1.0, 2)):
+        ref = fo.heun_sample(fo.conv_flow_apply, pq, x0.double(), lat.double(), n_steps, guidance_scale=gs)
+        out = heun_integrate(model, state.work, x0.cuda(), lat.cuda(), n_steps, guidance_scale=gs)
+        assert _rel(out, ref) < 2e-4, (gs, n_steps, _rel(out, ref))
