@@ -130,9 +130,7 @@ def symbol_of(name, ints, nn):
         T = "float" if dt == 0 else "unsigned short"
         tf = lambda b: "true" if b else "false"
         if dt == 1 and not (flags & 3) and K == 128 and M <= 256 and not (flags & 8):
-            mt = (((M + 15) // 16) + 3) // 4                                 # 16-row tiles per wave
-            nsub = 2 if (mt <= 3 and (N + 63) // 64 >= 4 * 512) else 1       # 64-column tiles per iteration (csrc/gemm.hip)
-            return f"gemm_nstream_kernel<{mt}, {nsub}>"
+            return f"gemm_nstream_kernel<{(((M + 15) // 16) + 3) // 4}>"   # 16-row tiles per wave
         return f"gemm_kernel<{T}, {32 if K <= 32 else 64}, {tf(flags & 1)}, {tf(flags & 2)}, {128 if M > 64 else 64}>"
     if name.startswith("mfc_cnx_"):
         T = "float" if ints[0] == 0 else "unsigned short"

@@ -406,7 +406,6 @@ gemm_kernel(GemmArgs g) {
 // the tangent of the fused LayerNorm in the same epilogue.
 // ---------------------------------------------------------------------------
 constexpr int NS_BN = 64, NS_K = 128, NS_KS = NS_K / 16, NS_LDR = 80, NS_MAXT = 4;
-constexpr int NS_CROW = 272;   // bytes per row of the NSUB == 2 output staging image (256 + 16: conflict-free b128 writes)
 struct NsPlan {
     // per wave: up to 4 16-row tiles of C, processed in order; kind 0 = plain, 1 = LN16 primal,
     // 2 = LN16 tangent of the entry before it
@@ -423,19 +422,13 @@ __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t by
 }
 constexpr uint32_t NS_OOB = 0xFFFFFF00u;
 
-// NSUB = 64-column tiles a workgroup handles per loop iteration.  With NSUB = 2 (MT <= 3: the accumulators of two tiles
-// fit under 256 registers) twice the bytes are in flight per workgroup and every barrier / wait is paid once per 128
-// columns: the loop is bound by the latency of the prefetched B tile, not by bandwidth (one tile in flight per workgroup
-// and two workgroups per CU are ~32 KB per CU; at ~2 us of loaded HBM latency that is ~4 TB/s chip-wide).
-template <int MT, int NSUB>
+template <int MT>
 __global__ void __launch_bounds__(GT)
 gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     typedef u16 T;
     typedef Frag<T>::type frag_t;
-    __shared__ __attribute__((aligned(16))) T Bs[NSUB][NS_K * NS_LDR];
-    __shared__ __attribute__((aligned(16))) float bias_s[NSUB][NS_BN];
-    // NSUB == 2: per wave [16 rows][256 B + 16 B pad] staging image of the output rows (see the epilogue)
-    __shared__ __attribute__((aligned(16))) unsigned char cstage[NSUB == 2 ? 4 * 16 * NS_CROW : 16];
+    __shared__ __attribute__((aligned(16))) T Bs[NS_K * NS_LDR];
+    __shared__ __attribute__((aligned(16))) float bias_s[NS_BN];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, r = lane & 15;
@@ -472,15 +465,13 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
         boff[p] = (uint32_t)((k * g.ldb + c8) * 2);
         lds_off[p] = k * NS_LDR + c8;
     }
-    u32x4 rb[NSUB][4];
-    // tiles past the end are clamped to the last one for LOADS (finite data, results never stored: see colok below)
-    auto load_b = [&](int sub, int64_t tile) {
-        const int64_t tl = tile < ntiles ? tile : ntiles - 1;
-        const int64_t n0 = tl * NS_BN;
+    u32x4 rb[4];
+    auto load_b = [&](int64_t tile) {
+        const int64_t n0 = tile * NS_BN;
         // columns >= N of rows < K-1 alias the next row (finite weights, results never stored); the last row is clipped
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(B + n0, (uint32_t)(((NS_K - 1) * g.ldb + (N - n0)) * 2));
 #pragma unroll
-        for (int p = 0; p < 4; ++p) rb[sub][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[p], 0, 0);
+        for (int p = 0; p < 4; ++p) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[p], 0, 0);
     };
 
     // The products are issued TRANSPOSED (C^T tile = B^T A^T: the weight tile is the MFMA A operand, the resident
@@ -490,186 +481,138 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     const int lr = r, lc = 16 * q;
     const bool has_alpha = g.alpha != 1.0f;
     const __amdgpu_buffer_rsrc_t rs_bias = make_rsrc(g.bias, g.bias ? (uint32_t)(N * 4) : 0u);
-    // Loop shape: the B tiles of iteration t+1 are requested at the top of iteration t and committed to LDS at its
+    // Loop shape: the B tile of iteration t+1 is requested at the top of iteration t and committed to LDS at its
     // bottom, so the wait sits in the same iteration as the request and only has to skip the VMEM instructions
     // issued in between (the epilogue stores) -- it never drains them.  The bias loads go first: vmcnt is in-order,
     // waiting for anything younger than the B request would wait for the B tile as well.
-    // Iteration `it` of a workgroup covers tiles NSUB * it .. NSUB * it + NSUB - 1.
-    const int64_t niter = (ntiles + NSUB - 1) / NSUB;
-    int64_t it = blockIdx.x;
-    if (it < niter) {
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) {
+        load_b(tile);
 #pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) load_b(sub, NSUB * it + sub);
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs[sub] + lds_off[p]) = rb[sub][p];
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs + lds_off[p]) = rb[p];
     }
     __syncthreads();
-    for (; it < niter; it += gridDim.x) {
-        // the tiles' 64 bias values each: 16 lanes x 16 bytes, parked in LDS after the MFMAs (no registers held across them)
-        u32x4 bias_v[NSUB];
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
-            const int64_t tile = NSUB * it + sub;
-            bias_v[sub] = __builtin_amdgcn_raw_buffer_load_b128(
-                rs_bias, (threadIdx.x < 16 && tile * NS_BN + 4 * threadIdx.x < N) ? (uint32_t)((tile * NS_BN + 4 * threadIdx.x) * 4) : NS_OOB, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep them OLDER than the B requests below (in-order vmcnt)
-        // prefetch (past the end: re-request this iteration's tiles, never committed -- keeps the instructions unconditional)
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int64_t col0 = tile * NS_BN + lc;
+        const bool colok = col0 < N;
+        // the tile's 64 bias values: 16 lanes x 16 bytes, parked in LDS after the MFMAs (no registers held across them)
+        const u32x4 bias_v = __builtin_amdgcn_raw_buffer_load_b128(
+            rs_bias, (threadIdx.x < 16 && tile * NS_BN + 4 * threadIdx.x < N) ? (uint32_t)((tile * NS_BN + 4 * threadIdx.x) * 4) : NS_OOB, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // keep it OLDER than the B request below (in-order vmcnt)
+        // prefetch (past the end: re-request this tile, never committed -- keeps the instruction unconditional)
         {
-            const int64_t nit = it + gridDim.x < niter ? it + gridDim.x : it;
-#pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub) load_b(sub, NSUB * nit + sub);
+            const int64_t nt = tile + gridDim.x < ntiles ? tile + gridDim.x : tile;
+            load_b(nt);
         }
 
-        f32x4 acc[NSUB][MT][4];
+        f32x4 acc[MT][4];
 #pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub)
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NS_KS; ++c) {
+            frag_t bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // LDS transpose read: lane 4q'+p of group q supplies k-row 4q+q', columns 16p + 4j .. +3
+                const T* bp = Bs + (16 * c + 4 * q + (r >> 2)) * NS_LDR + 16 * (r & 3) + 4 * j;
+                bf[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[sub][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub)
-#pragma unroll
-            for (int c = 0; c < NS_KS; ++c) {
-                frag_t bf[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // LDS transpose read: lane 4q'+p of group q supplies k-row 4q+q', columns 16p + 4j .. +3
-                    const T* bp = Bs[sub] + (16 * c + 4 * q + (r >> 2)) * NS_LDR + 16 * (r & 3) + 4 * j;
-                    bf[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
-                }
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) mma16(acc[sub][i][j], bf[j], af[i][c]);
-            }
-        if (threadIdx.x < 16) {
-#pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub) *reinterpret_cast<u32x4*>(bias_s[sub] + 4 * threadIdx.x) = bias_v[sub];
+                for (int j = 0; j < 4; ++j) mma16(acc[i][j], bf[j], af[i][c]);
         }
-        __syncthreads();   // B tiles consumed: the next iteration may overwrite them while slower waves are in the epilogue
+        if (threadIdx.x < 16) *reinterpret_cast<u32x4*>(bias_s + 4 * threadIdx.x) = bias_v;
+        __syncthreads();   // B tile consumed: the next iteration may overwrite it while slower waves are in the epilogue
 
-        // epilogue: one lane = 16 consecutive columns of one row per 64-column tile, straight from the accumulators.
-        // NSUB == 2: the two tiles' 32-byte pieces of a row are gathered in a wave-private LDS image [16 rows][256 B] and
-        // leave as four 256-byte row segments per store instruction (16 lanes x 16 B per row) instead of sixteen 64-byte
-        // ones -- the access shape that lifted the AdamW epilogue from 5.2 to 5.9 TB/s.
-        uint32_t npr[NSUB][8];       // the normalised primal of a (primal, tangent) tile pair, as stored (bf16 pairs)
-        float rho_pr[NSUB];
+        // epilogue: one lane = 16 consecutive columns of one row, straight from the accumulators
+        uint32_t npr[8];       // the normalised primal of a (primal, tangent) tile pair, as stored (bf16 pairs)
+        float rho_pr = 0.f;
 #pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
-            rho_pr[sub] = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) npr[sub][k] = 0u;
-        }
+        for (int k = 0; k < 8; ++k) npr[k] = 0u;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[i][j][e];
             // wave-uniform geometry of this 16-row tile (a wave without an i-th tile gets an empty resource)
             const int64_t row0 = 16 * (int64_t)(mt[i] < 0 ? 0 : mt[i]);
             const int64_t rows_valid = mt[i] < 0 ? 0 : (g.M - row0 < 16 ? g.M - row0 : 16);
             const int64_t rows_bias = g.bias_rows - row0;      // rows [0, rows_bias) of the tile take the bias
+            if (rows_bias > 0) {
+                const bool hb = lr < rows_bias;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + lc + 4 * k4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[4 * k4 + k] += hb ? b4[k] : 0.f;
+                }
+            }
+            if (has_alpha) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] *= g.alpha;
+            }
+            if (kind[i] == 1) {
+                rho_pr = ln16_lane(v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) npr[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+            } else if (kind[i] == 2) {
+                float n[16];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    n[2 * k] = __builtin_bit_cast(float, (uint32_t)(npr[k] << 16));
+                    n[2 * k + 1] = __builtin_bit_cast(float, (uint32_t)(npr[k] & 0xffff0000u));
+                }
+                ln16_tangent_lane(v, n, rho_pr);
+            }
+            {   // 1/sigma of the LN16 primal rows (empty resource otherwise)
+                const uint32_t bytes = kind[i] == 1 ? (uint32_t)(rows_valid * (N >> 4) * 4) : 0u;
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(g.ln_rstd ? g.ln_rstd + row0 * (N >> 4) : nullptr, g.ln_rstd ? bytes : 0u);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, rho_pr), rs,
+                                                      colok ? (uint32_t)((lr * (N >> 4) + (col0 >> 4)) * 4) : NS_OOB, 0, 0);
+            }
             const uint32_t cbytes = rows_valid > 0 ? (uint32_t)(((rows_valid - 1) * g.ldc + N) * 2) : 0u;
-            const __amdgpu_buffer_rsrc_t rs_c = make_rsrc((T*)g.C + row0 * g.ldc, cbytes);
-#pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub) {
-                const int64_t tile = NSUB * it + sub;
-                const int64_t col0 = tile * NS_BN + lc;
-                const bool colok = tile < ntiles && col0 < N;
-                float v[16];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[sub][i][j][e];
-                if (rows_bias > 0) {
-                    const bool hb = lr < rows_bias;
-#pragma unroll
-                    for (int k4 = 0; k4 < 4; ++k4) {
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s[sub] + lc + 4 * k4);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[4 * k4 + k] += hb ? b4[k] : 0.f;
-                    }
-                }
-                if (has_alpha) {
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) v[k] *= g.alpha;
-                }
-                if (kind[i] == 1) {
-                    rho_pr[sub] = ln16_lane(v);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) npr[sub][k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
-                } else if (kind[i] == 2) {
-                    float n[16];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        n[2 * k] = __builtin_bit_cast(float, (uint32_t)(npr[sub][k] << 16));
-                        n[2 * k + 1] = __builtin_bit_cast(float, (uint32_t)(npr[sub][k] & 0xffff0000u));
-                    }
-                    ln16_tangent_lane(v, n, rho_pr[sub]);
-                }
-                {   // 1/sigma of the LN16 primal rows (empty resource otherwise)
-                    const uint32_t bytes = kind[i] == 1 ? (uint32_t)(rows_valid * (N >> 4) * 4) : 0u;
-                    const __amdgpu_buffer_rsrc_t rs = make_rsrc(g.ln_rstd ? g.ln_rstd + row0 * (N >> 4) : nullptr, g.ln_rstd ? bytes : 0u);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, rho_pr[sub]), rs,
-                                                          colok ? (uint32_t)((lr * (N >> 4) + (col0 >> 4)) * 4) : NS_OOB, 0, 0);
-                }
-                const uint32_t coff = colok ? (uint32_t)((lr * g.ldc + col0) * 2) : NS_OOB;
-                if (g.R) {
-                    const uint32_t rbytes = rows_valid > 0 ? (uint32_t)(((rows_valid - 1) * g.ldr + N) * 2) : 0u;
-                    const __amdgpu_buffer_rsrc_t rs = make_rsrc((const T*)g.R + row0 * g.ldr, rbytes);
-                    const uint32_t roff = colok ? (uint32_t)((lr * g.ldr + col0) * 2) : NS_OOB;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, roff + 16 * h, 0, 0);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            v[8 * h + 2 * k] += g.beta * __builtin_bit_cast(float, (uint32_t)(t[k] << 16));
-                            v[8 * h + 2 * k + 1] += g.beta * __builtin_bit_cast(float, (uint32_t)(t[k] & 0xffff0000u));
-                        }
-                    }
-                }
-                if (g.accum) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_c, coff + 16 * h, 0, 0);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            v[8 * h + 2 * k] += __builtin_bit_cast(float, (uint32_t)(t[k] << 16));
-                            v[8 * h + 2 * k + 1] += __builtin_bit_cast(float, (uint32_t)(t[k] & 0xffff0000u));
-                        }
-                    }
-                }
+            const uint32_t coff = colok ? (uint32_t)((lr * g.ldc + col0) * 2) : NS_OOB;
+            if (g.R) {
+                const uint32_t rbytes = rows_valid > 0 ? (uint32_t)(((rows_valid - 1) * g.ldr + N) * 2) : 0u;
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc((const T*)g.R + row0 * g.ldr, rbytes);
+                const uint32_t roff = colok ? (uint32_t)((lr * g.ldr + col0) * 2) : NS_OOB;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const u32x4 t = {pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
-                                     pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
-                    if constexpr (NSUB == 2)
-                        *reinterpret_cast<u32x4*>(cstage + (wave * 16 + lr) * NS_CROW + sub * 128 + 2 * lc + 16 * h) = t;
-                    else
-                        __builtin_amdgcn_raw_buffer_store_b128(t, rs_c, coff + 16 * h, 0, 0);
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, roff + 16 * h, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[8 * h + 2 * k] += g.beta * __builtin_bit_cast(float, (uint32_t)(t[k] << 16));
+                        v[8 * h + 2 * k + 1] += g.beta * __builtin_bit_cast(float, (uint32_t)(t[k] & 0xffff0000u));
+                    }
                 }
             }
-            if constexpr (NSUB == 2) {
-                // LDS operations of one wave execute in order: only the compiler must keep the reads below the writes
-                asm volatile("" ::: "memory");
-                const int64_t colb = NSUB * it * NS_BN;           // first column of the 128-column pair
-                const int chunk = lane & 15;                       // 16-byte chunk (8 columns) of the 256-byte row segment
-                const bool cok = colb + 8 * chunk < N;
+            const __amdgpu_buffer_rsrc_t rs_c = make_rsrc((T*)g.C + row0 * g.ldc, cbytes);
+            if (g.accum) {
 #pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const int rr = 4 * h + (lane >> 4);
-                    const u32x4 t = *reinterpret_cast<const u32x4*>(cstage + (wave * 16 + rr) * NS_CROW + 16 * chunk);
-                    __builtin_amdgcn_raw_buffer_store_b128(t, rs_c, cok ? (uint32_t)((rr * g.ldc + colb + 8 * chunk) * 2) : NS_OOB, 0, 0);
+                for (int h = 0; h < 2; ++h) {
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_c, coff + 16 * h, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[8 * h + 2 * k] += __builtin_bit_cast(float, (uint32_t)(t[k] << 16));
+                        v[8 * h + 2 * k + 1] += __builtin_bit_cast(float, (uint32_t)(t[k] & 0xffff0000u));
+                    }
                 }
-                asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32x4 t = {pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                                 pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+                __builtin_amdgcn_raw_buffer_store_b128(t, rs_c, coff + 16 * h, 0, 0);
             }
         }
-        // commit the prefetched B tiles (every wave left the MFMA loop at the barrier above)
+        // commit the prefetched B tile (every wave left the MFMA loop at the barrier above)
 #pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs[sub] + lds_off[p]) = rb[sub][p];
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs + lds_off[p]) = rb[p];
         __syncthreads();
     }
 }
@@ -841,10 +784,6 @@ inline bool ns_disabled() {
     static const bool off = [] { const char* e = getenv("MFC_GEMM_NSTREAM"); return e && e[0] == '0'; }();
     return off;
 }
-inline bool ns_two_tiles() {      // MFC_GEMM_NS_SUB=1: one tile per iteration (A/B switch)
-    static const bool on = [] { const char* e = getenv("MFC_GEMM_NS_SUB"); return !(e && e[0] == '1'); }();
-    return on;
-}
 inline int64_t ns_max_blocks() {
     static const int64_t n = [] { const char* e = getenv("MFC_GEMM_NS_BLOCKS"); const long v = e ? atol(e) : 0; return (int64_t)(v > 0 ? v : 512); }();
     return n;
@@ -956,24 +895,12 @@ int gemm_impl(int dtype, int flags, int64_t M, int64_t N, int64_t K, const void*
         const int mt = ns_make_plan(M, bias_rows, ln, ln_tan, plan);
         if (mt > 0) {
             const int64_t ntiles = ceil_div64(N, NS_BN);
-            // two tiles per iteration when the accumulators fit (MT <= 3) and there is enough work to fill the grid twice
-            const int nsub = (mt <= 3 && ns_two_tiles() && ntiles >= 4 * ns_max_blocks()) ? 2 : 1;
-            const int64_t niter = ceil_div64(ntiles, nsub);
-            int64_t grid = niter < ns_max_blocks() ? niter : ns_max_blocks();
-            const dim3 gd((unsigned)grid), bd(GT);
-            if (nsub == 2) {
-                switch (mt) {
-                    case 1: hipLaunchKernelGGL((gemm_nstream_kernel<1, 2>), gd, bd, 0, st, g, plan, ntiles); break;
-                    case 2: hipLaunchKernelGGL((gemm_nstream_kernel<2, 2>), gd, bd, 0, st, g, plan, ntiles); break;
-                    default: hipLaunchKernelGGL((gemm_nstream_kernel<3, 2>), gd, bd, 0, st, g, plan, ntiles); break;
-                }
-            } else {
-                switch (mt) {
-                    case 1: hipLaunchKernelGGL((gemm_nstream_kernel<1, 1>), gd, bd, 0, st, g, plan, ntiles); break;
-                    case 2: hipLaunchKernelGGL((gemm_nstream_kernel<2, 1>), gd, bd, 0, st, g, plan, ntiles); break;
-                    case 3: hipLaunchKernelGGL((gemm_nstream_kernel<3, 1>), gd, bd, 0, st, g, plan, ntiles); break;
-                    default: hipLaunchKernelGGL((gemm_nstream_kernel<4, 1>), gd, bd, 0, st, g, plan, ntiles); break;
-                }
+            int64_t grid = ntiles < ns_max_blocks() ? ntiles : ns_max_blocks();
+            switch (mt) {
+                case 1: hipLaunchKernelGGL((gemm_nstream_kernel<1>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles); break;
+                case 2: hipLaunchKernelGGL((gemm_nstream_kernel<2>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles); break;
+                case 3: hipLaunchKernelGGL((gemm_nstream_kernel<3>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles); break;
+                default: hipLaunchKernelGGL((gemm_nstream_kernel<4>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles); break;
             }
             return mfc_launch_status();
         }
