@@ -125,10 +125,14 @@ int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
  * exchange between jax.value_and_grad and optax.adamw, trainers/training_steps.py:32-33):
  *   g = grad_scale * op(A)[M,K] . op(B)[K,N]   (rounded to bf16, as the two-kernel path stores it)
  *   m, v, p <- AdamW(g)  (mfc_adamw's arithmetic; fp32 [M,N] dense);  p_bf16[M,N] <- bf16(p)
- * bf16 operands; N % 16 == 0 and 16-byte aligned buffers, else MFC_ENOSYS (use mfc_gemm + mfc_adamw). */
+ * bf16 operands; N % 16 == 0 and 16-byte aligned buffers, else MFC_ENOSYS (use mfc_gemm + mfc_adamw).
+ * colsum (may be NULL): fp32 [N], overwritten with colsum_scale * sum_k B[k][n] -- the bias gradient of the same
+ * Dense layer when B = dY (value_and_grad gives dW = X^T dY and db = sum_rows dY together); needs a non-transposed B
+ * and K > 32, else MFC_ENOSYS.  Fixed-order sums (deterministic). */
 int mfc_gemm_adamw(int flags, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                    int64_t ldb, float grad_scale, float* p, float* m, float* v, void* p_bf16, float lr,
-                   float b1, float b2, float eps, float wd, int64_t step, void* stream);
+                   float b1, float b2, float eps, float wd, int64_t step, float* colsum, float colsum_scale,
+                   void* stream);
 
 /* ------------------------------------------------------------------ */
 /* ConvNeXt block interior (models/conv_flow.py:65-115,162-186)        */

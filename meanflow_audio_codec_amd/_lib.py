@@ -50,7 +50,7 @@ SIGNATURES = {
     "mfc_cnx_max_blocks": (c_int64, [c_int64]),
     "mfc_gemm_ws_elems": (c_int64, [c_int, c_int64, c_int64, c_int64, c_int]),
     "mfc_gemm_adamw": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, c_float, _P, _P, _P, _P,
-                               c_float, c_float, c_float, c_float, c_float, c_int64, _P]),
+                               c_float, c_float, c_float, c_float, c_float, c_int64, _P, c_float, _P]),
     "mfc_cnx_stats": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_grn_finalize": (c_int, [c_int64, _P, _P, _P, _P, _P, _P]),
     "mfc_cnx_apply": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -48,6 +48,10 @@ struct GemmArgs {
     // mfc_gemm_adamw: the product is a weight gradient and the epilogue is the AdamW update of that weight
     float* opt_p; float* opt_m; float* opt_v;   // fp32 master and moments, dense [M, N]; C = the bf16 working copy
     float lr, b1, b2, eps, wd, bc1, bc2;
+    // mfc_gemm_adamw, optional: column sums of the (non-transposed, bf16) B operand, colsum[n] = colsum_scale * sum_k B[k][n]
+    // -- the bias gradient that belongs to this weight gradient (B = dY): the operand is in LDS anyway, so the separate
+    // pass over dY (1.6 GB for the [128, S] kernels) disappears.  Written by the workgroups of the first M tile only.
+    float* colsum; float colsum_scale;
 };
 
 template <typename T> struct Vec;   // 16-byte global vector
@@ -292,6 +296,12 @@ gemm_kernel(GemmArgs g) {
     SA::load(A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
     SB::load(B, g.ldb, n0, g.N, kbeg, kend, g.vecB, rb);
 
+    // column sums of the B tile (bias gradient, see GemmArgs::colsum): thread (kg, cg) adds k-rows 4 kg .. 4 kg + 3 of
+    // columns 8 cg .. 8 cg + 7 of every K-step; only bf16, row-contiguous B ([BK][LDR] image), first M tile
+    constexpr bool CAN_COLSUM = sizeof(T) == 2 && !TB && BK == 64;
+    const bool do_colsum = CAN_COLSUM && g.colsum != nullptr && m0 == 0 && blockIdx.z == 0;
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
         SA::store(As, ra);
         SB::store(Bs, rb);
@@ -299,6 +309,17 @@ gemm_kernel(GemmArgs g) {
         if (k0 + BK < kend) {   // next tile's global loads fly during the MFMAs
             SA::load(A, g.lda, m0, g.M, k0 + BK, kend, g.vecA, ra);
             SB::load(B, g.ldb, n0, g.N, k0 + BK, kend, g.vecB, rb);
+        }
+        if constexpr (CAN_COLSUM) {
+            if (do_colsum) {       // (rows past kend were staged as zeros)
+                const int cg = threadIdx.x & 15, kg = threadIdx.x >> 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const s16x8 v = *reinterpret_cast<const s16x8*>(Bs + (4 * kg + i) * SB::LDR + 8 * cg);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) csum[e] += bf16_to_f32((u16)v[e]);
+                }
+            }
         }
 #pragma unroll
         for (int c = 0; c < BK / 16; ++c) {
@@ -315,6 +336,31 @@ gemm_kernel(GemmArgs g) {
                 for (int j = 0; j < 4; ++j) mma16(acc[i][j], af[i], bf[j]);
         }
         __syncthreads();
+    }
+
+    if constexpr (CAN_COLSUM) {
+        if (do_colsum) {
+            // fixed order: the 4 k-groups of a wave by two shuffles, then the 4 waves through LDS (the operand tiles are
+            // free: the K loop ended on a barrier)
+            float* red = reinterpret_cast<float*>(lds);          // [4 waves][128 columns]
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = csum[e];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                csum[e] = v;
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[wave * 128 + 8 * lane + e] = csum[e];
+            }
+            __syncthreads();
+            if (threadIdx.x < 128 && n0 + threadIdx.x < g.N) {
+                const int c = threadIdx.x;
+                g.colsum[n0 + c] = g.colsum_scale * (((red[c] + red[128 + c]) + red[256 + c]) + red[384 + c]);
+            }
+            __syncthreads();
+        }
     }
 
     // epilogue.  C layout of a 16x16 MFMA tile: col = lane&15, row = 4*(lane>>4)+reg
@@ -792,7 +838,7 @@ inline int64_t ns_max_blocks() {
 }  // namespace
 
 namespace {
-struct OptArgs { float* p; float* m; float* v; float lr, b1, b2, eps, wd, bc1, bc2; };
+struct OptArgs { float* p; float* m; float* v; float lr, b1, b2, eps, wd, bc1, bc2; float* colsum; float colsum_scale; };
 int gemm_impl(int dtype, int flags, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
               int64_t ldb, void* C, int64_t ldc, const float* bias, int64_t bias_rows, int64_t act_rows, float alpha,
               const void* R, int64_t ldr, float beta_res, int splitk, float* ws, float* ln_rstd, const OptArgs* opt,
@@ -827,10 +873,12 @@ extern "C" int mfc_gemm(int dtype, int flags, int64_t M, int64_t N, int64_t K,
 
 extern "C" int mfc_gemm_adamw(int flags, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                               int64_t ldb, float grad_scale, float* p, float* m, float* v, void* p_bf16, float lr,
-                              float b1, float b2, float eps, float wd, int64_t step, void* stream) {
+                              float b1, float b2, float eps, float wd, int64_t step, float* colsum, float colsum_scale,
+                              void* stream) {
     if (!p || !m || !v || !p_bf16) return MFC_EFAULT;
     if (step < 1 || (flags & ~(MFC_GEMM_TRANS_A | MFC_GEMM_TRANS_B))) return MFC_EINVAL;
-    OptArgs o{p, m, v, lr, b1, b2, eps, wd, 1.0f - powf(b1, (float)step), 1.0f - powf(b2, (float)step)};
+    if (colsum && ((flags & MFC_GEMM_TRANS_B) || K <= 32)) return MFC_ENOSYS;     // needs the [k][n] LDS image of B, BK = 64
+    OptArgs o{p, m, v, lr, b1, b2, eps, wd, 1.0f - powf(b1, (float)step), 1.0f - powf(b2, (float)step), colsum, colsum_scale};
     return gemm_impl(MFC_BF16, flags, M, N, K, A, lda, B, ldb, p_bf16, N, nullptr, 0, M, grad_scale, nullptr, 0, 0.f, 1,
                      nullptr, nullptr, &o, stream);
 }
@@ -873,11 +921,13 @@ int gemm_impl(int dtype, int flags, int64_t M, int64_t N, int64_t K, const void*
              (!R || (((ldr * es) % 16 == 0) && (((uintptr_t)R % 16) == 0)));
     g.opt_p = g.opt_m = g.opt_v = nullptr;
     g.lr = g.b1 = g.b2 = g.eps = g.wd = g.bc1 = g.bc2 = 0.f;
+    g.colsum = nullptr; g.colsum_scale = 0.f;
     if (opt) {
         // the fused update lives in the row-contiguous epilogue of the tiled kernel
         if (!g.vecC || use_ws || (((uintptr_t)opt->p | (uintptr_t)opt->m | (uintptr_t)opt->v) & 15)) return MFC_ENOSYS;
         g.opt_p = opt->p; g.opt_m = opt->m; g.opt_v = opt->v;
         g.lr = opt->lr; g.b1 = opt->b1; g.b2 = opt->b2; g.eps = opt->eps; g.wd = opt->wd; g.bc1 = opt->bc1; g.bc2 = opt->bc2;
+        g.colsum = opt->colsum; g.colsum_scale = opt->colsum_scale;
     }
     g.ln_rstd = nullptr;
     if (flags & MFC_GEMM_LN16) {

@@ -260,8 +260,14 @@ class ConditionalConvFlow:
         product that READS such a kernel is therefore issued before the one that updates it.
         Returns (dx [R,D], dcond [R,cond] fp32)."""
         def dw(name, A, dY, alpha=1.0):
+            """weight gradient of leaf ``name`` (= A^T dY) and the bias gradient of the same layer (column sums of dY):
+            fused single-GPU steps get both from one kernel (mfc_gemm_adamw with its colsum output)."""
+            bias = name[:-len("kernel")] + "bias"
+            if fused is not None and fused.dw(name, A, dY, alpha, bias_out=grads[bias], bias_scale=alpha):
+                return
             if fused is None or not fused.dw(name, A, dY, alpha):
                 dense_dw(A, dY, alpha=alpha, out=grads[name])
+            ops.colsum(dY, scale=alpha, out=grads[bias])
         R, K, S, s, T = ctx.R, self.num_blocks, self.S, self.spatial_size, self.dtype
         D, dev = self.noise_dimension, dout.device
         assert dout.shape == (R, D) and dout.dtype == T and dout.is_contiguous()
@@ -278,11 +284,9 @@ class ConditionalConvFlow:
             # out = (g2 W4 + b4)/K + x
             dg2 = dense_dx(dX, w[f"{b}/output_proj2/kernel"], alpha=1.0 / K)
             dw(f"{b}/output_proj2/kernel", g2, dX, 1.0 / K)
-            ops.colsum(dX, scale=1.0 / K, out=grads[f"{b}/output_proj2/bias"])
             da2 = ops.gelu_bwd(a2, dg2)
             dense_dx(da2, w[f"{b}/output_proj1/kernel"], out=dO)
             dw(f"{b}/output_proj1/kernel", O, da2)
-            ops.colsum(da2, out=grads[f"{b}/output_proj1/bias"])
             # ConvNeXt interior
             cg = self._cnx_g(grads, i)
             for t_ in cg.values():
@@ -294,11 +298,9 @@ class ConditionalConvFlow:
             ops.colsum(dcp, out=grads[f"{b}/conditioning_layer/bias"])
             dcond = dense_dx(dcp, w[f"{b}/conditioning_layer/kernel"], residual=dcond, beta=1.0)
             # h0 = g1 W2 + b2
-            ops.colsum(dH0, out=grads[f"{b}/input_proj2/bias"])
             dg1 = dense_dx(dH0, w[f"{b}/input_proj2/kernel"])
             dw(f"{b}/input_proj2/kernel", g1, dH0)
             da1 = ops.gelu_bwd(a1, dg1)
-            ops.colsum(da1, out=grads[f"{b}/input_proj1/bias"])
             dX = dense_dx(da1, w[f"{b}/input_proj1/kernel"], residual=dX, beta=1.0)
             dw(f"{b}/input_proj1/kernel", x_in, da1)
             if on_block is not None:

@@ -8,6 +8,7 @@ keeps working.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import torch
@@ -156,12 +157,17 @@ class FusedUpdater:
         return (w is not None and w.dtype == torch.bfloat16 and w.dim() == 2 and w.shape[1] % 16 == 0
                 and name not in self.done)
 
-    def dw(self, name: str, A: torch.Tensor, dY: torch.Tensor, alpha: float = 1.0) -> bool:
+    def dw(self, name: str, A: torch.Tensor, dY: torch.Tensor, alpha: float = 1.0, bias_out: torch.Tensor | None = None,
+           bias_scale: float = 1.0) -> bool:
+        """``bias_out``: also write the bias gradient of the same Dense layer, ``bias_scale`` x the column sums of
+        ``dY``, from the operand tiles the product stages (needs at least 33 rows: the 64-deep K-step kernel)."""
         if not self.wants(name) or A.dtype != torch.bfloat16 or dY.dtype != torch.bfloat16:
+            return False
+        if bias_out is not None and (dY.shape[0] <= 32 or os.environ.get("MFC_BIAS_FOLD", "1") == "0"):
             return False
         st, tx = self.state, self.state.tx
         ops.gemm_adamw(A, dY, trans_a=True, grad_scale=alpha, p=st.params[name], m=st.opt_state["mu"][name],
                        v=st.opt_state["nu"][name], p_bf16=st.work[name], lr=tx.learning_rate, wd=tx.weight_decay,
-                       step=st.step, b1=tx.b1, b2=tx.b2, eps=tx.eps)
+                       step=st.step, b1=tx.b1, b2=tx.b2, eps=tx.eps, colsum=bias_out, colsum_scale=bias_scale)
         self.done.add(name)
         return True

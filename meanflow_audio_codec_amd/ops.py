@@ -53,10 +53,12 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a=False, trans_b=False, bias
 
 
 def gemm_adamw(A, B, *, p, m, v, p_bf16, lr, wd, step, trans_a=False, trans_b=False, grad_scale=1.0, b1=0.9,
-               b2=0.999, eps=1e-8) -> None:
+               b2=0.999, eps=1e-8, colsum=None, colsum_scale=1.0) -> None:
     """Weight gradient op(A) op(B) fused with the AdamW update of that weight (``mfc_gemm_adamw``): updates the fp32
     master ``p``, the moments ``m``/``v`` and the bf16 working copy ``p_bf16`` in place; bit-identical to
-    ``gemm(..., out=g_bf16)`` followed by ``adamw(p, g_bf16, ...)``."""
+    ``gemm(..., out=g_bf16)`` followed by ``adamw(p, g_bf16, ...)``.  ``colsum`` (fp32 [N]): overwritten with
+    ``colsum_scale`` x the column sums of ``B`` (the bias gradient when ``B`` = dY), computed from the operand tiles the
+    product stages anyway."""
     _lib.require_cuda(A, B)
     assert A.dtype == B.dtype == torch.bfloat16 and A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
     M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
@@ -66,9 +68,12 @@ def gemm_adamw(A, B, *, p, m, v, p_bf16, lr, wd, step, trans_a=False, trans_b=Fa
         assert t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == M * N
     assert p_bf16.dtype == torch.bfloat16 and p_bf16.is_contiguous() and p_bf16.numel() == M * N
     flags = (GEMM_TRANS_A if trans_a else 0) | (GEMM_TRANS_B if trans_b else 0)
+    if colsum is not None:
+        assert colsum.dtype == torch.float32 and colsum.is_contiguous() and colsum.numel() == N and not trans_b
     rc = _lib.lib().mfc_gemm_adamw(flags, M, N, K, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), float(grad_scale),
                                    p.data_ptr(), m.data_ptr(), v.data_ptr(), p_bf16.data_ptr(), float(lr), float(b1),
-                                   float(b2), float(eps), float(wd), int(step), _lib.stream_ptr())
+                                   float(b2), float(eps), float(wd), int(step), _lib.ptr(colsum), float(colsum_scale),
+                                   _lib.stream_ptr())
     _lib.check(rc, "mfc_gemm_adamw")
 
 

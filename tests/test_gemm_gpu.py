@@ -180,3 +180,39 @@ def test_gemm_adamw_fused_equals_gemm_then_adamw(M, N, K):
         ops.gemm_adamw(X, dY, trans_a=True, grad_scale=0.5, p=pb, m=mb, v=vb, p_bf16=wb, lr=1e-2, wd=1e-2, step=step)
         assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(wa, wb), step
     assert (pa - torch.randn(M, N, generator=torch.Generator(device="cuda").manual_seed(21), device="cuda")).abs().max() >= 0
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 64, 128), (128, 4000, 130), (1000, 128, 96), (256, 144, 33)])
+def test_gemm_adamw_bias_gradient_output(M, N, K):
+    """The ``colsum`` output of mfc_gemm_adamw (the Dense layer's bias gradient, scale x column sums of dY, taken from the
+    B tiles the product stages): equals the standalone mfc_colsum to fp32 rounding, leaves the fused update bit-identical,
+    and is itself reproducible bit for bit.  K <= 32 selects the 32-deep kernel, which has no such output: ENOSYS."""
+    from meanflow_audio_codec_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    X = (torch.randn(K, M, generator=g, device="cuda") * 0.3).bfloat16()
+    dY = (torch.randn(K, N, generator=g, device="cuda") * 0.1).bfloat16()
+    p0 = torch.randn(M, N, generator=g, device="cuda")
+    outs = []
+    for cs in (None, torch.full((N,), float("nan"), device="cuda"), torch.full((N,), 7.0, device="cuda")):
+        p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+        w = p.bfloat16()
+        ops.gemm_adamw(X, dY, trans_a=True, grad_scale=0.25, p=p, m=m, v=v, p_bf16=w, lr=1e-2, wd=1e-2, step=1, colsum=cs,
+                       colsum_scale=0.25)
+        outs.append((p, m, v, w, cs))
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[1][4], outs[2][4])                                   # overwritten, not accumulated; bitwise
+    ref = 0.25 * dY.double().sum(0)
+    assert (outs[1][4].double() - ref).abs().max().item() <= 1e-6 * max(1.0, dY.double().abs().sum(0).max().item())
+    sep = ops.colsum(dY, scale=0.25)
+    assert (outs[1][4] - sep).abs().max().item() <= 1e-6 * max(1.0, dY.double().abs().sum(0).max().item())
+
+
+def test_gemm_adamw_bias_gradient_needs_the_deep_kernel():
+    from meanflow_audio_codec_amd import ops
+    X = torch.zeros(32, 64, device="cuda", dtype=torch.bfloat16)
+    dY = torch.zeros(32, 64, device="cuda", dtype=torch.bfloat16)
+    p = torch.zeros(64, 64, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.gemm_adamw(X, dY, trans_a=True, p=p, m=p.clone(), v=p.clone(), p_bf16=p.bfloat16(), lr=1e-3, wd=0.0, step=1,
+                       colsum=torch.zeros(64, device="cuda"))
