@@ -314,7 +314,8 @@ int mfc_adaln_fwd(int dtype, int64_t rows, int64_t act_rows, int64_t W, const vo
                   const void* scale, const void* shift, int64_t ldm, int64_t mod_div, void* y,
                   int64_t ldy, void* stream);
 /* reverse pass: dx, dscale = dy*LN(x), dshift = dy.  mod_div == 1: dscale/dshift dtype [rows, W]
- * (ldd); mod_div > 1: fp32 [rows/mod_div, W] accumulated with atomics (zeroed by the caller). */
+ * (ldd); mod_div > 1: fp32 [rows/mod_div, W], OVERWRITTEN with the sum over the mod_div rows of each group taken in
+ * ascending row order (a second kernel, one workgroup per group: bitwise reproducible, no atomics). */
 int mfc_adaln_bwd(int dtype, int64_t rows, int64_t W, const void* x, int64_t ldx, const void* scale,
                   int64_t ldm, int64_t mod_div, const void* dy, int64_t ldy, void* dx, void* dscale,
                   void* dshift, int64_t ldd, void* stream);

@@ -50,7 +50,7 @@ def build(force: bool = False, verbose: bool = True, jobs: int = 4) -> pathlib.P
     def cc(job):
         src, obj = job
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", str(src), "-o", str(obj),
-               "-Wall", "-Wno-unused-function", "-munsafe-fp-atomics", "-Wno-inline-asm",
+               "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
                "-mllvm", "-amdgpu-mfma-vgpr-form=1",   # MFMA results straight into VGPRs (no v_accvgpr_read traffic)
                # no SLP vectorisation: it turns adjacent scalar f32 ops into v_pk_{mul,add,fma}_f32, which on gfx950
                # issue slower than the two scalar instructions they replace (MI355X_MICROARCH.md, packed f32 VALU) and

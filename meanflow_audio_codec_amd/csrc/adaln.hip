@@ -73,8 +73,8 @@ __global__ void __launch_bounds__(AT) adaln_fwd_kernel(AdaArgs a) {
 }
 
 // reverse: dscale = dy * n ; dshift = dy ; dx = LN-bwd(dy * (1 + scale))
-// mod_div > 1 (modulation shared by mod_div rows): dscale/dshift are reduced with fp32 atomics into
-// [rows/mod_div, W] fp32 buffers (zeroed by the caller); mod_div == 1: written in T.
+// mod_div == 1: dscale/dshift written in T by this kernel.  mod_div > 1 (modulation shared by mod_div rows): they are
+// fp32 [rows/mod_div, W] buffers written by adaln_bwd_mod_kernel below (fixed summation order, no atomics).
 template <typename T>
 __global__ void __launch_bounds__(AT) adaln_bwd_kernel(AdaArgs a) {
     __shared__ float red[AT / 64];
@@ -105,10 +105,45 @@ __global__ void __launch_bounds__(AT) adaln_bwd_kernel(AdaArgs a) {
         if (a.mod_div == 1) {
             St<T>::st((T*)a.dscale + row * a.ldd + c, dyv * n);
             St<T>::st((T*)a.dshift + row * a.ldd + c, dyv);
-        } else {
-            atomicAdd((float*)a.dscale + (row / a.mod_div) * a.ldd + c, dyv * n);
-            atomicAdd((float*)a.dshift + (row / a.mod_div) * a.ldd + c, dyv);
         }
+    }
+}
+
+// dscale / dshift of a modulation shared by mod_div consecutive rows: one workgroup per group.  The rows' LayerNorm
+// statistics are recomputed in batches into LDS, then every thread sums its columns over the rows of the batch in
+// ascending row order -- bitwise reproducible (the sums used to be fp32 atomics).
+constexpr int MOD_BATCH = 1024;
+template <typename T>
+__global__ void __launch_bounds__(AT) adaln_bwd_mod_kernel(AdaArgs a) {
+    __shared__ float red[AT / 64];
+    __shared__ float st_mean[MOD_BATCH], st_rho[MOD_BATCH];
+    const int64_t grp = blockIdx.x, W = a.W;
+    const int64_t r0 = grp * a.mod_div, r1 = (r0 + a.mod_div < a.rows) ? r0 + a.mod_div : a.rows;
+    float* ds = (float*)a.dscale + grp * a.ldd;
+    float* dh = (float*)a.dshift + grp * a.ldd;
+    for (int64_t b0 = r0; b0 < r1; b0 += MOD_BATCH) {
+        const int nb = (int)((r1 - b0 < MOD_BATCH) ? r1 - b0 : MOD_BATCH);
+        for (int i = 0; i < nb; ++i) {
+            const T* xp = (const T*)a.x + (b0 + i) * a.ldx;
+            float s = 0.f, ss = 0.f;
+            for (int64_t c = threadIdx.x; c < W; c += AT) { const float v = St<T>::ld(xp + c); s += v; ss += v * v; }
+            const float mean = block_sum(s, red) / (float)W;
+            const float var = fmaxf(0.f, block_sum(ss, red) / (float)W - mean * mean);
+            if (threadIdx.x == 0) { st_mean[i] = mean; st_rho[i] = rsqrtf(var + 1e-6f); }
+        }
+        __syncthreads();
+        for (int64_t c = threadIdx.x; c < W; c += AT) {
+            float acc_s = (b0 == r0) ? 0.f : ds[c], acc_h = (b0 == r0) ? 0.f : dh[c];
+            for (int i = 0; i < nb; ++i) {
+                const float n = (St<T>::ld((const T*)a.x + (b0 + i) * a.ldx + c) - st_mean[i]) * st_rho[i];
+                const float dyv = St<T>::ld((const T*)a.dy + (b0 + i) * a.ldy + c);
+                acc_s += dyv * n;
+                acc_h += dyv;
+            }
+            ds[c] = acc_s;
+            dh[c] = acc_h;
+        }
+        __syncthreads();
     }
 }
 
@@ -236,6 +271,11 @@ extern "C" int mfc_adaln_bwd(int dtype, int64_t rows, int64_t W, const void* x, 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MFC_F32) hipLaunchKernelGGL(adaln_bwd_kernel<float>, dim3((unsigned)rows), dim3(AT), 0, st, a);
     else hipLaunchKernelGGL(adaln_bwd_kernel<u16>, dim3((unsigned)rows), dim3(AT), 0, st, a);
+    if (mod_div > 1) {
+        const unsigned groups = (unsigned)((rows + mod_div - 1) / mod_div);
+        if (dtype == MFC_F32) hipLaunchKernelGGL(adaln_bwd_mod_kernel<float>, dim3(groups), dim3(AT), 0, st, a);
+        else hipLaunchKernelGGL(adaln_bwd_mod_kernel<u16>, dim3(groups), dim3(AT), 0, st, a);
+    }
     return mfc_launch_status();
 }
 

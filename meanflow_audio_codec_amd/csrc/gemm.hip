@@ -240,7 +240,7 @@ __device__ inline float ln16_lane(float v[16]) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) { sum += v[k]; sq += v[k] * v[k]; }
     const float mean = sum * (1.0f / 16.0f);
-    const float rho = rsqrtf(fmaxf(0.0f, sq * (1.0f / 16.0f) - mean * mean) + 1e-6f);
+    const float rho = __builtin_amdgcn_rsqf(fmaxf(0.0f, sq * (1.0f / 16.0f) - mean * mean) + 1e-6f);   // argument >= 1e-6: no denormal path
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = (v[k] - mean) * rho;
     return rho;

@@ -69,7 +69,7 @@ class _MixerBlock:
         dh2 = ops.gelu_bwd(h2, dense_dx(dx2, w[f"{p}/Dense_5/kernel"]))
         dense_dw(a2, dh2, out=grads[f"{p}/Dense_4/kernel"]); ops.colsum(dh2, out=grads[f"{p}/Dense_4/bias"])
         da2 = dense_dx(dh2, w[f"{p}/Dense_4/kernel"])
-        dmod2 = torch.zeros((R, 2 * C), dtype=torch.float32, device=dev)
+        dmod2 = torch.empty((R, 2 * C), dtype=torch.float32, device=dev)
         dx1 = ops.adaln_bwd(x1, mod2[:R, :C], da2, dmod2[:, :C], dmod2[:, C:], mod_div=nt)
         dx1 = ops.axpby(1.0, dx1, 1.0, dx2)
         dense_dw(cond, dmod2, out=grads[f"{p}/Dense_3/kernel"]); ops.colsum(dmod2, out=grads[f"{p}/Dense_3/bias"])
@@ -80,7 +80,7 @@ class _MixerBlock:
         dh = ops.gelu_bwd(h, dense_dx(dtk, w[f"{p}/Dense_2/kernel"]))
         dense_dw(aT, dh, out=grads[f"{p}/Dense_1/kernel"]); ops.colsum(dh, out=grads[f"{p}/Dense_1/bias"])
         da = ops.transpose(dense_dx(dh, w[f"{p}/Dense_1/kernel"]), R, C, nt).view(R * nt, C)
-        dmod1 = torch.zeros((R, 2 * C), dtype=torch.float32, device=dev)
+        dmod1 = torch.empty((R, 2 * C), dtype=torch.float32, device=dev)
         dX = ops.adaln_bwd(X, mod1[:R, :C], da, dmod1[:, :C], dmod1[:, C:], mod_div=nt)
         dX = ops.axpby(1.0, dX, 1.0, dx1)
         dense_dw(cond, dmod1, out=grads[f"{p}/Dense_0/kernel"]); ops.colsum(dmod1, out=grads[f"{p}/Dense_0/bias"])
