@@ -59,6 +59,9 @@ def parse():
                     help="weak (default): the config's batch 128 on EVERY GPU (global 128*N); strong: SURVEY 8(e)'s "
                          "partition, global batch 128 split 128/N per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-loss-probe", action="store_true",
+                    help="skip the two untimed unweighted-MSE evaluations (profiling runs: every launch in the process then "
+                         "belongs to a training step, so rocprofv3's per-symbol averages are those of the step)")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--decode-batch", type=int, default=None)
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (no roofline)")
@@ -144,10 +147,14 @@ def symbol_of(name, ints, nn):
     return name.replace("mfc_", "") + "_kernel"
 
 
+PMC_TABLE = "r02_final_pmc_traffic.json"
+
+
 def measured_traffic(symbol):
-    """average HBM bytes per launch of a kernel symbol from the committed rocprofv3 PMC passes, or None."""
+    """average HBM bytes per launch of a kernel symbol from the committed rocprofv3 PMC passes of this round
+    (profiles/r02_final_pmc_traffic.json, made by tools/pmc_traffic.py), or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_TABLE)) as f:
             tab = json.load(f)
         e = tab.get(symbol)
         return None if e is None else e["avg_hbm_bytes_per_launch"]
@@ -471,7 +478,7 @@ def main():
         torch.cuda.synchronize()
 
     def unweighted_mse():
-        if rank != 0:
+        if rank != 0 or args.no_loss_probe:
             return None
         try:
             aux = {}

@@ -37,7 +37,10 @@ extern "C" {
 #define MFC_F32 0
 #define MFC_BF16 1
 
-/* library / ABI version and a one-line description of the build */
+/* library / ABI version and a one-line description of the build.  Version 2 (round 2): row_stride / data_size arguments
+ * of mfc_sample_tr and mfc_flow_prepare, caller-owned workspaces instead of atomics (mfc_gemm_ws_elems,
+ * mfc_cnx_ws_elems, MFC_FLOW_LOSS_WS_PER_ROW), colsum output of mfc_gemm_adamw. */
+#define MFC_ABI_VERSION 2
 int mfc_abi_version(void);
 const char* mfc_build_info(void);
 

@@ -34,6 +34,7 @@ _lib = None
 # name -> (restype, argtypes); kept in sync with include/mfc.h by
 # tests/test_capi_symbols.py
 _P = c_void_p
+ABI_VERSION = 2          # MFC_ABI_VERSION of include/mfc.h
 SIGNATURES = {
     "mfc_abi_version": (c_int, []),
     "mfc_build_info": (c_char_p, []),
@@ -167,6 +168,9 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        if l.mfc_abi_version() != ABI_VERSION:     # a stale build would take the new arguments as garbage pointers
+            raise MfcError(f"{LIB_PATH} has ABI version {l.mfc_abi_version()}, this package binds version {ABI_VERSION}: "
+                           "rebuild with `python -m meanflow_audio_codec_amd._build --force`")
         _lib = l
     _proxy = _Proxy(_lib)
     return _proxy

@@ -1351,25 +1351,36 @@ cnx_reduce_rows_kernel(const float* ws, Geo g, int rec, int off, int n, int n0, 
     else out1[r * (n - n0) + c - n0] = v;
 }
 
-// Parameter gradients: dst[i] += sum over all `nrec` records, ascending, of rec[off + i].  Tree with a fixed shape: 16
-// waves each sum the records congruent to their index mod 16 (64 consecutive elements per wave instruction), then the
-// 16 partial sums are added in wave order.
+// Parameter gradients: dst[i] += sum over all `nrec` records of rec[off + i], in a tree of fixed shape: a workgroup owns
+// 16 consecutive elements; its 64 slots (16 waves x 4 quarter-waves) each sum the records congruent to their index mod
+// 64 with four independent accumulators (the loads of one slot are serial otherwise: the first version of this kernel
+// spent 72 us per launch on 64 dependent L2 round trips), and the 64 partial sums are added in slot order.
 struct RedSeg { float* dst; int begin, end; };     // record elements [begin, end) -> dst[0 .. end - begin)
 struct RedSegs { RedSeg s[4]; int n; };
+constexpr int RB_ELEMS = 16, RB_SLOTS = 64;
 __global__ void __launch_bounds__(1024)
 cnx_reduce_blocks_kernel(const float* ws, int64_t nrec, int rec, int total, RedSegs segs) {
-    __shared__ float part[16][64];
-    const int il = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + il;
-    float v = 0.f;
-    if (i < total)
-        for (int64_t b = w; b < nrec; b += 16) v += ws[b * rec + i];
-    part[w][il] = v;
+    __shared__ float part[RB_SLOTS][RB_ELEMS + 1];
+    const int il = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const int i = blockIdx.x * RB_ELEMS + il;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (i < total) {
+        const float* p = ws + i;
+        int64_t b = slot;
+        for (; b + 3 * RB_SLOTS < nrec; b += 4 * RB_SLOTS) {
+            v0 += p[b * rec];
+            v1 += p[(b + RB_SLOTS) * rec];
+            v2 += p[(b + 2 * RB_SLOTS) * rec];
+            v3 += p[(b + 3 * RB_SLOTS) * rec];
+        }
+        for (; b < nrec; b += RB_SLOTS) v0 += p[b * rec];
+    }
+    part[slot][il] = (v0 + v1) + (v2 + v3);
     __syncthreads();
-    if (w == 0 && i < total) {
+    if (slot == 0 && i < total) {
         float sum = part[0][il];
-#pragma unroll
-        for (int k = 1; k < 16; ++k) sum += part[k][il];
+#pragma unroll 8
+        for (int k = 1; k < RB_SLOTS; ++k) sum += part[k][il];
         for (int k = 0; k < segs.n; ++k)
             if (i >= segs.s[k].begin && i < segs.s[k].end) segs.s[k].dst[i - segs.s[k].begin] += sum;
     }
@@ -1495,7 +1506,7 @@ inline int reduce_rows(const float* ws, const Geo& g, int rec, int off, int n, i
     return mfc_launch_status();
 }
 inline int reduce_blocks(const float* ws, int64_t nrec, int rec, int total, const RedSegs& segs, hipStream_t st) {
-    hipLaunchKernelGGL(cnx_reduce_blocks_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, st, ws, nrec, rec,
+    hipLaunchKernelGGL(cnx_reduce_blocks_kernel, dim3((unsigned)((total + RB_ELEMS - 1) / RB_ELEMS)), dim3(1024), 0, st, ws, nrec, rec,
                        total, segs);
     return mfc_launch_status();
 }

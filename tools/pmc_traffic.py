@@ -2,7 +2,7 @@
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch --output-format csv -- python3 bench.py --steps 1 --warmup 1 \
-        --no-cpu-baseline --no-decode --no-kernel-timing --no-overlap
+        --no-cpu-baseline --no-decode --no-kernel-timing --no-overlap --no-loss-probe
     rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write --output-format csv -- python3 bench.py ... (same)
     python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_final
 
@@ -62,7 +62,7 @@ def main(argv):
         json.dump(by_launch, f, indent=1)
     table = {"_comment": "average HBM bytes per launch per kernel symbol = sum over launches of (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                          "/ launches, from two separate rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE) over `python3 bench.py "
-                         "--steps 1 --warmup 1 --no-cpu-baseline --no-decode --no-kernel-timing --no-overlap` (literal config, 1x "
+                         "--steps 1 --warmup 1 --no-cpu-baseline --no-decode --no-kernel-timing --no-overlap --no-loss-probe` (literal config, 1x "
                          "MI355X; x2 on FETCH_SIZE = the gfx950 correction of MI355X_MICROARCH.md); made by tools/pmc_traffic.py. "
                          f"Launches present in only one pass: {unmatched}."}
     for k, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
