@@ -305,6 +305,24 @@ int mfc_adamw(int grad_dtype, int64_t n, float* p, void* p_bf16, const void* g, 
               float* m, float* v, float lr, float b1, float b2, float eps, float wd, int64_t step,
               void* stream);
 
+/* The same update for many (small) leaves in one launch per MFC_ADAMW_MULTI_MAX items: `items` is a HOST array of
+ * n_items descriptors (copied into the kernel arguments; nothing is read from it after the call returns); element
+ * arithmetic and results identical to one mfc_adamw per leaf.  A ConvFlow step has ~170 leaves below a million
+ * elements (biases, conv kernels, GRN / layer-scale vectors): this replaces their ~6 us launches. */
+typedef struct mfc_adamw_item {
+    float* p;          /* fp32 master [n] */
+    void* p_bf16;      /* optional bf16 working copy [n] (NULL: none) */
+    const void* g;     /* gradient [n], grad_dtype */
+    float* m;          /* fp32 moments [n] */
+    float* v;
+    int64_t n;
+    int32_t grad_dtype; /* MFC_F32 / MFC_BF16 */
+    int32_t reserved;
+} mfc_adamw_item;
+#define MFC_ADAMW_MULTI_MAX 48
+int mfc_adamw_multi(int n_items, const mfc_adamw_item* items, float grad_scale, float lr, float b1, float b2,
+                    float eps, float wd, int64_t step, void* stream);
+
 /* ------------------------------------------------------------------ */
 /* AdaLN / gating (MLP and MLP-Mixer velocity nets)                    */
 /* ------------------------------------------------------------------ */

@@ -35,6 +35,14 @@ _lib = None
 # tests/test_capi_symbols.py
 _P = c_void_p
 ABI_VERSION = 2          # MFC_ABI_VERSION of include/mfc.h
+
+
+class AdamwItem(ctypes.Structure):
+    """``mfc_adamw_item`` of include/mfc.h"""
+    _fields_ = [("p", c_void_p), ("p_bf16", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p),
+                ("n", c_int64), ("grad_dtype", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 SIGNATURES = {
     "mfc_abi_version": (c_int, []),
     "mfc_build_info": (c_char_p, []),
@@ -60,6 +68,7 @@ SIGNATURES = {
     "mfc_grn_bwd_finalize": (c_int, [c_int64, _P, _P, _P, _P, _P]),
     "mfc_cnx_bwd_main": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_cnx_bwd_conv": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_adamw_multi": (c_int, [c_int, _P, c_float, c_float, c_float, c_float, c_float, c_float, c_int64, _P]),
     "mfc_adaln_fwd": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, _P]),
     "mfc_adaln_bwd": (c_int, [c_int, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int64, _P, c_int64, _P, _P, _P,
                               c_int64, _P]),

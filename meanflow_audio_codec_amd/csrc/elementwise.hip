@@ -535,6 +535,64 @@ extern "C" int mfc_cast(int src_dtype, int dst_dtype, int64_t n, const void* x, 
     return mfc_launch_status();
 }
 
+// ---- multi-tensor AdamW: one launch for up to MFC_ADAMW_MULTI_MAX leaves ----------------------------------------
+// The descriptors travel in the kernel arguments; a workgroup owns MT_SPAN consecutive elements of one leaf and finds
+// its leaf by a linear scan of the block prefix (<= 48 entries, uniform across the workgroup).
+namespace {
+constexpr int MT_SPAN = 4 * ET;
+struct AdamwMultiArgs {
+    mfc_adamw_item it[MFC_ADAMW_MULTI_MAX];
+    uint32_t first_block[MFC_ADAMW_MULTI_MAX + 1];
+    int n_items;
+    float gscale, lr, b1, b2, eps, wd, bc1, bc2;
+};
+__global__ void __launch_bounds__(ET) adamw_multi_kernel(AdamwMultiArgs a) {
+    int k = 0;
+    while (k + 1 < a.n_items && blockIdx.x >= a.first_block[k + 1]) ++k;
+    const mfc_adamw_item& it = a.it[k];
+    const int64_t base = (int64_t)(blockIdx.x - a.first_block[k]) * MT_SPAN;
+    u16* pw = (u16*)it.p_bf16;
+#pragma unroll
+    for (int i = 0; i < MT_SPAN / ET; ++i) {
+        const int64_t o = base + i * ET + threadIdx.x;
+        if (o >= it.n) break;
+        const float g = it.grad_dtype == MFC_F32 ? ((const float*)it.g)[o] : bf16_to_f32(((const u16*)it.g)[o]);
+        float pv = it.p[o], mv = it.m[o], vv = it.v[o];
+        adamw_elem(pv, mv, vv, g * a.gscale, a.lr, a.b1, a.b2, a.eps, a.wd, a.bc1, a.bc2);
+        it.p[o] = pv; it.m[o] = mv; it.v[o] = vv;
+        if (pw) pw[o] = f32_to_bf16(pv);
+    }
+}
+}  // namespace
+
+extern "C" int mfc_adamw_multi(int n_items, const mfc_adamw_item* items, float grad_scale, float lr, float b1, float b2,
+                               float eps, float wd, int64_t step, void* stream) {
+    if (n_items < 0 || step < 1) return MFC_EINVAL;
+    if (n_items > 0 && !items) return MFC_EFAULT;
+    for (int i = 0; i < n_items; ++i) {
+        if (!items[i].p || !items[i].g || !items[i].m || !items[i].v) return MFC_EFAULT;
+        if (items[i].n <= 0 || !DT_OK(items[i].grad_dtype) || ceil_div64(items[i].n, MT_SPAN) > (1LL << 30)) return MFC_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    for (int i0 = 0; i0 < n_items; i0 += MFC_ADAMW_MULTI_MAX) {
+        AdamwMultiArgs a;
+        a.n_items = n_items - i0 < MFC_ADAMW_MULTI_MAX ? n_items - i0 : MFC_ADAMW_MULTI_MAX;
+        uint64_t blocks = 0;
+        for (int k = 0; k < a.n_items; ++k) {
+            a.it[k] = items[i0 + k];
+            a.first_block[k] = (uint32_t)blocks;
+            blocks += (uint64_t)ceil_div64(items[i0 + k].n, MT_SPAN);
+        }
+        for (int k = a.n_items; k < MFC_ADAMW_MULTI_MAX; ++k) { a.it[k] = mfc_adamw_item{}; a.first_block[k] = (uint32_t)blocks; }
+        a.first_block[MFC_ADAMW_MULTI_MAX] = (uint32_t)blocks;
+        if (blocks > 0x7fffffffULL) return MFC_EINVAL;
+        a.gscale = grad_scale; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.wd = wd;
+        a.bc1 = 1.0f - powf(b1, (float)step); a.bc2 = 1.0f - powf(b2, (float)step);
+        hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)blocks), dim3(ET), 0, st, a);
+    }
+    return mfc_launch_status();
+}
+
 extern "C" int mfc_adamw(int grad_dtype, int64_t n, float* p, void* p_bf16, const void* g, float grad_scale,
                          float* m, float* v, float lr, float b1, float b2, float eps, float wd, int64_t step,
                          void* stream) {

@@ -107,7 +107,7 @@ class TrainState:
             for k, p in self.params.items():
                 dt = self._work_dtype(k)
                 if "/conv_block/" in k:
-                    dt = torch.float32   # accumulated with fp32 atomics by the spatial kernels
+                    dt = torch.float32   # fp32 accumulators (+=) of the spatial kernels' fixed-order reductions
                 g[k] = torch.zeros(p.shape, dtype=dt, device=p.device)
             self._grads = g
         return self._grads
@@ -123,23 +123,42 @@ class TrainState:
         """Start one optimizer step whose leaves are updated piecewise with ``apply_subset``."""
         self.step += 1
 
+    # leaves below this many elements share launches (mfc_adamw_multi); larger ones take the vectorised mfc_adamw
+    MULTI_TENSOR_BELOW = 1 << 20
+
     def apply_subset(self, names, grads: dict, grad_scale: float = 1.0):
+        """AdamW on the named leaves (``self.step`` is the 1-based update count, already advanced by the caller).  On
+        the GPU the small leaves -- biases, conv kernels, GRN / layer-scale vectors: ~170 of a ConvFlow's 200 -- go
+        through one ``mfc_adamw_multi`` launch per 48 instead of a 6 us launch each; the descriptor table of a
+        (names, gradient buffers) combination is built once and reused (every tensor in it is updated in place)."""
         tx = self.tx
+        hp = dict(lr=tx.learning_rate, wd=tx.weight_decay, step=self.step, b1=tx.b1, b2=tx.b2, eps=tx.eps,
+                  grad_scale=grad_scale)
+        names = list(names)
+        small = [k for k in names if self.params[k].is_cuda and self.params[k].numel() < self.MULTI_TENSOR_BELOW]
+        if len(small) > 1:
+            mu = self.opt_state["mu"]
+            key = (tuple(small), tuple((grads[k].data_ptr(), self.params[k].data_ptr(), mu[k].data_ptr()) for k in small))
+            cache = self.__dict__.setdefault("_multi_cache", {})
+            ent = cache.get(key)
+            if ent is None:
+                leaves = [(self.params[k], grads[k], self.opt_state["mu"][k], self.opt_state["nu"][k],
+                           self.work[k] if self.work[k].dtype == torch.bfloat16 else None) for k in small]
+                if len(cache) > 16:
+                    cache.clear()
+                ent = cache[key] = (ops.adamw_multi_items(leaves), leaves)      # the tensors stay alive with the table
+            (items, n), _ = ent
+            ops.adamw_multi(items, n, **hp)
+            small = set(small)
+            names = [k for k in names if k not in small]
         for k in names:
             p, g, w = self.params[k], grads[k], self.work[k]
-            ops.adamw(p, g, self.opt_state["mu"][k], self.opt_state["nu"][k], lr=tx.learning_rate,
-                      wd=tx.weight_decay, step=self.step, b1=tx.b1, b2=tx.b2, eps=tx.eps,
-                      p_bf16=(w if w.dtype == torch.bfloat16 else None), grad_scale=grad_scale)
+            ops.adamw(p, g, self.opt_state["mu"][k], self.opt_state["nu"][k],
+                      p_bf16=(w if w.dtype == torch.bfloat16 else None), **hp)
 
     def apply_gradients(self, *, grads: dict, grad_scale: float = 1.0):
         self.step += 1
-        tx = self.tx
-        for k, p in self.params.items():
-            g = grads[k]
-            w = self.work[k]
-            ops.adamw(p, g, self.opt_state["mu"][k], self.opt_state["nu"][k], lr=tx.learning_rate,
-                      wd=tx.weight_decay, step=self.step, b1=tx.b1, b2=tx.b2, eps=tx.eps,
-                      p_bf16=(w if w.dtype == torch.bfloat16 else None), grad_scale=grad_scale)
+        self.apply_subset(list(self.params), grads, grad_scale)
         return self
 
 

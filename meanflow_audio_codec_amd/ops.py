@@ -1,6 +1,8 @@
 """Thin torch-tensor wrappers over the C ABI (no arithmetic here)."""
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -378,6 +380,33 @@ def adamw(p, g, m, v, *, lr, wd, step, b1=0.9, b2=0.999, eps=1e-8, p_bf16=None, 
                                     g.data_ptr(), float(grad_scale), m.data_ptr(), v.data_ptr(), float(lr),
                                     float(b1), float(b2), float(eps), float(wd), int(step), _lib.stream_ptr()),
                "mfc_adamw")
+
+
+def adamw_multi_items(leaves):
+    """Descriptor table for ``adamw_multi``: ``leaves`` = iterable of (p, g, m, v, p_bf16 or None).  The table holds raw
+    device pointers: build it once for buffers that live as long as the train state (masters, moments, working copies
+    and the persistent gradient buffers are updated in place) and keep the tensors alive beside it."""
+    leaves = list(leaves)
+    arr = (_lib.AdamwItem * max(1, len(leaves)))()
+    for it, (p, g, m, v, w) in zip(arr, leaves):
+        assert p.dtype == torch.float32 and m.dtype == torch.float32 and v.dtype == torch.float32
+        assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+        assert g.numel() == p.numel() == m.numel() == v.numel() and p.is_cuda
+        if w is not None:
+            assert w.dtype == torch.bfloat16 and w.is_contiguous() and w.numel() == p.numel()
+        it.p, it.p_bf16, it.g, it.m, it.v = p.data_ptr(), _lib.ptr(w), g.data_ptr(), m.data_ptr(), v.data_ptr()
+        it.n, it.grad_dtype = p.numel(), _lib.dtype_code(g.dtype)
+    return arr, len(leaves)
+
+
+def adamw_multi(items, n_items, *, lr, wd, step, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
+    """``mfc_adamw_multi``: the AdamW update of many small leaves in one launch per 48 leaves (same element arithmetic
+    as ``adamw``)."""
+    if n_items == 0:
+        return
+    _lib.check(_lib.lib().mfc_adamw_multi(int(n_items), ctypes.addressof(items), float(grad_scale), float(lr), float(b1),
+                                          float(b2), float(eps), float(wd), int(step), _lib.stream_ptr()),
+               "mfc_adamw_multi")
 
 
 # ---------------------------------------------------------------------------

@@ -55,3 +55,13 @@ def test_argument_checks_fail_loudly_without_launching():
     assert l.mfc_mdct_fwd(None, 1, 10, 10, 8, 4, None, None) == -14
     assert l.mfc_gemm(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, ctypes.c_float(1.0), None, 0,
                       ctypes.c_float(0.0), 1, None, None, None) == -14
+
+
+def test_adamw_multi_argument_checks():
+    l = _lib.lib()
+    f = ctypes.c_float
+    assert l.mfc_adamw_multi(-1, None, f(1), f(1e-3), f(.9), f(.999), f(1e-8), f(0), 1, None) == -22
+    assert l.mfc_adamw_multi(2, None, f(1), f(1e-3), f(.9), f(.999), f(1e-8), f(0), 1, None) == -14
+    items = (_lib.AdamwItem * 1)()            # null pointers inside a descriptor
+    assert l.mfc_adamw_multi(1, ctypes.addressof(items), f(1), f(1e-3), f(.9), f(.999), f(1e-8), f(0), 1, None) == -14
+    assert ctypes.sizeof(_lib.AdamwItem) == 56

@@ -171,3 +171,33 @@ def test_adamw_unaligned_views():
     pc, gc, mc, vc = pb[1:].clone(), gr[1:].clone(), m2[1:].clone(), v2[1:].clone()  # aligned copies
     ops.adamw(pc, gc, mc, vc, lr=1e-2, wd=1e-2, step=1)
     assert torch.equal(pa[1:], pc) and torch.equal(m1[1:], mc) and torch.equal(v1[1:], vc)
+
+
+def test_adamw_multi_equals_one_launch_per_leaf():
+    """mfc_adamw_multi (one launch per 48 leaves, descriptors in the kernel arguments) == mfc_adamw leaf by leaf, bit
+    for bit: odd sizes, fp32 and bf16 gradients, with and without a bf16 working copy, more than one chunk of leaves,
+    several steps on the same table (the table holds raw pointers of tensors that are updated in place)."""
+    import torch
+    from meanflow_audio_codec_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    sizes = [1, 3, 16, 255, 256, 1000, 1024, 4099, 65537] + [7 * (i + 1) for i in range(50)]
+    a, b = [], []
+    for i, n in enumerate(sizes):
+        p = torch.randn(n, generator=g, device="cuda")
+        gdt = torch.bfloat16 if i % 3 == 0 else torch.float32
+        w = p.bfloat16() if i % 2 == 0 else None
+        a.append([p.clone(), None, torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), None if w is None else w.clone(), gdt])
+        b.append([p.clone(), None, torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), None if w is None else w.clone(), gdt])
+    grads = [torch.empty(n, device="cuda", dtype=l[5]) for n, l in zip(sizes, a)]
+    items, cnt = ops.adamw_multi_items([(l[0], gr, l[2], l[3], l[4]) for l, gr in zip(b, grads)])
+    assert cnt == len(sizes) > 48
+    for step in range(1, 4):
+        for gr in grads:
+            gr.copy_(torch.randn(gr.shape, generator=g, device="cuda") * 0.1)
+        for l, gr in zip(a, grads):
+            ops.adamw(l[0], gr, l[2], l[3], lr=1e-2, wd=1e-2, step=step, p_bf16=l[4], grad_scale=0.5)
+        ops.adamw_multi(items, cnt, lr=1e-2, wd=1e-2, step=step, grad_scale=0.5)
+        for la, lb in zip(a, b):
+            assert torch.equal(la[0], lb[0]) and torch.equal(la[2], lb[2]) and torch.equal(la[3], lb[3])
+            if la[4] is not None:
+                assert torch.equal(la[4], lb[4])
