@@ -218,8 +218,10 @@ int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h1, const float* r
                      const float* shift, const mfc_cnx_params* p, const void* dc1, const void* dout,
                      void* dh0, const mfc_cnx_grads* g, float* dscale, float* dshift, float* ws, void* stream);
 
-/* Tuning / test hook: the persistent ConvNeXt kernels launch at most this many workgroups (default 2048, env
- * MFC_CNX_MAX_BLOCKS), each walking a contiguous range of tiles.  n > 0 sets it; returns the previous value. */
+/* Tuning / test hook: the persistent ConvNeXt kernels launch at most this many workgroups, each walking a contiguous
+ * range of tiles.  Default 0 = a per-kernel multiple of the resident workgroups (512 .. 3072); n > 0 (or env
+ * MFC_CNX_MAX_BLOCKS) forces one value for every kernel, n = 0 restores the defaults; returns the previous value.
+ * mfc_cnx_ws_elems follows the current setting: size the workspace after changing it. */
 int64_t mfc_cnx_max_blocks(int64_t n);
 
 /* First LayerNorm of the block (conv_flow.py:181, nn.LayerNorm over the 16 channels of each pixel):

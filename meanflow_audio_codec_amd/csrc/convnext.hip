@@ -163,6 +163,20 @@ __device__ inline void ln_fwd_centered(const float v[4], float n[4], float& rho)
 #pragma unroll
     for (int i = 0; i < 4; ++i) n[i] = v[i] * rho;
 }
+// f32x4 forms (packed f32 VALU for the normalisation; the sum of squares stays a scalar fma chain)
+__device__ inline f32x4 ln_fwd_centered4(f32x4 v, float& rho) {
+#if defined(MFC_CNX_ABL) && (MFC_CNX_ABL & 4)
+    const float ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];     // ablation: no cross-lane ladder
+#else
+    const float ss = red_q(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+#endif
+    rho = __builtin_amdgcn_rsqf(ss * (1.0f / 16.0f) + LN_EPS);
+    return v * splat4(rho);
+}
+__device__ inline f32x4 ln_jvp_centered4(f32x4 vd, f32x4 n, float rho) {
+    const float dot = red_q(n[0] * vd[0] + n[1] * vd[1] + n[2] * vd[2] + n[3] * vd[3]) * (1.0f / 16.0f);
+    return fma4(n, splat4(-dot), vd) * splat4(rho);
+}
 // ... and its tangent for a centred tangent vd (the tangent conv uses the same centred weights): mean(vd) = 0
 __device__ inline void ln_jvp_centered(const float vd[4], const float n[4], float rho, float nd[4]) {
     const float dot = red_q(n[0] * vd[0] + n[1] * vd[1] + n[2] * vd[2] + n[3] * vd[3]) * (1.0f / 16.0f);
@@ -557,8 +571,13 @@ __device__ inline void chain_row(const T* tile, const T* tiled, const T* wc0, co
     }
     if constexpr (K32W && sizeof(T) == 2) {
         const int band = y * (Halo<T>::CPP * HW * Halo<T>::EPC);
+#if defined(MFC_CNX_ABL) && (MFC_CNX_ABL & 2)
+        constexpr int NPR = 1;                    // ablation: one of the five conv steps (LDS reads + MFMAs)
+#else
+        constexpr int NPR = 5;
+#endif
 #pragma unroll
-        for (int pr = 0; pr < 5; ++pr) {          // taps (2p, 2p+1) and (8, -): one K = 32 step each (see mma32)
+        for (int pr = 0; pr < NPR; ++pr) {          // taps (2p, 2p+1) and (8, -): one K = 32 step each (see mma32)
             const s16x8 a = *reinterpret_cast<const s16x8*>(tile + band + w.xo[pr]);
             mma32(acc, rw.w2[pr], a);
             if constexpr (JVP) {
@@ -582,28 +601,28 @@ __device__ inline void chain_row(const T* tile, const T* tiled, const T* wc0, co
                 }
             }
     }
-    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-    ln_fwd_centered(v, o.n1, o.rho1);
-    make_frag(o.n1f, o.n1[0], o.n1[1], o.n1[2], o.n1[3]);
+    const f32x4 n1v = ln_fwd_centered4(acc, o.rho1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.n1[i] = n1v[i];
+    make_frag(o.n1f, n1v[0], n1v[1], n1v[2], n1v[3]);
     if constexpr (JVP) {
-        float vd[4] = {accd[0], accd[1], accd[2], accd[3]}, nd[4];
-        ln_jvp_centered(vd, o.n1, o.rho1, nd);
+        const f32x4 nd = ln_jvp_centered4(accd, n1v, o.rho1);
         make_frag(o.n1df, nd[0], nd[1], nd[2], nd[3]);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        f32x4 e = f32x4{w.be[j][0], w.be[j][1], w.be[j][2], w.be[j][3]};
+        f32x4 e = ld_f32x4(w.be[j]);
         mma16(e, w.we[j], o.n1f);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if constexpr (WG || JVP) { float gv, gpv; gelu_both(e[i], gv, gpv); o.g[j][i] = gv; o.gp[j][i] = gpv; }
-            else o.g[j][i] = gelu_f(e[i]);
-        }
+#if defined(MFC_CNX_ABL) && (MFC_CNX_ABL & 1)
+        o.g[j] = e; o.gp[j] = e;          // ablation: no GELU arithmetic
+#else
+        if constexpr (WG || JVP) gelu_both4(e, o.g[j], o.gp[j]);
+        else o.g[j] = gelu4(e);
+#endif
         if constexpr (JVP) {
             f32x4 ed = f32x4{0.f, 0.f, 0.f, 0.f};
             mma16(ed, w.we[j], o.n1df);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o.gd[j][i] = ed[i] * o.gp[j][i];
+            o.gd[j] = ed * o.gp[j];
         }
     }
 }
@@ -660,8 +679,9 @@ cnx_fwd_kernel(FwdArgs a) {
     int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
     int64_t t1 = t0 + a.geo.chunk < a.geo.total ? t0 + a.geo.chunk : a.geo.total;
     int64_t rcur = -1;
-    float s1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, s2[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    float qv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, qdv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 s1[2] = {z4, z4}, s2[2] = {z4, z4};
+    f32x4 gq[2] = {z4, z4}, qdv[2] = {z4, z4};       // apply mode: gamma + q (the GRN scale of this row r), qdot
     __amdgpu_buffer_rsrc_t rs_o = make_rsrc(nullptr, 0), rs_od = make_rsrc(nullptr, 0);
 
     int krow = 0;            // rows flushed so far = index of the next record of this workgroup
@@ -713,13 +733,15 @@ cnx_fwd_kernel(FwdArgs a) {
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        qv[j][i] = a.q[r * 32 + 16 * j + 4 * q + i];
+                        gq[j][i] = a.q[r * 32 + 16 * j + 4 * q + i];
                         if constexpr (JVP) qdv[j][i] = a.qd[r * 32 + 16 * j + 4 * q + i];
                     }
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { land(qv[j][i]); if constexpr (JVP) land(qdv[j][i]); }
+                for (int j = 0; j < 2; ++j) {
+                    land(gq[j]);
+                    if constexpr (JVP) land(qdv[j]);
+                    gq[j] = gq[j] + ld_f32x4(w.gam[j]);
+                }
                 rs_o = make_rsrc((const T*)a.o + r * img, (uint32_t)(img * sizeof(T)));
                 if constexpr (JVP) {
                     rs_od = make_rsrc((const T*)a.od + r * img, (uint32_t)(img * sizeof(T)));
@@ -748,29 +770,23 @@ cnx_fwd_kernel(FwdArgs a) {
             if constexpr (MODE == 0) {
                 if (ok) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            s1[j][i] += f.g[j][i] * f.g[j][i];
-                            if constexpr (JVP) s2[j][i] += f.g[j][i] * f.gd[j][i];
-                        }
+                    for (int j = 0; j < 2; ++j) {
+                        s1[j] = fma4(f.g[j], f.g[j], s1[j]);
+                        if constexpr (JVP) s2[j] = fma4(f.g[j], f.gd[j], s2[j]);
+                    }
                 }
             } else {
-                f32x4 p1 = f32x4{w.bp[0], w.bp[1], w.bp[2], w.bp[3]}, p1d = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 p1 = ld_f32x4(w.bp), p1d = z4;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     frag_t yf;
-                    make_frag(yf, f.g[j][0] * (w.gam[j][0] + qv[j][0]) + w.bet[j][0],
-                              f.g[j][1] * (w.gam[j][1] + qv[j][1]) + w.bet[j][1],
-                              f.g[j][2] * (w.gam[j][2] + qv[j][2]) + w.bet[j][2],
-                              f.g[j][3] * (w.gam[j][3] + qv[j][3]) + w.bet[j][3]);
+                    const f32x4 yv = fma4(f.g[j], gq[j], ld_f32x4(w.bet[j]));
+                    make_frag(yf, yv[0], yv[1], yv[2], yv[3]);
                     mma16(p1, w.wp[j], yf);
                     if constexpr (JVP) {
                         frag_t ydf;
-                        make_frag(ydf, f.gd[j][0] * (w.gam[j][0] + qv[j][0]) + f.g[j][0] * qdv[j][0],
-                                  f.gd[j][1] * (w.gam[j][1] + qv[j][1]) + f.g[j][1] * qdv[j][1],
-                                  f.gd[j][2] * (w.gam[j][2] + qv[j][2]) + f.g[j][2] * qdv[j][2],
-                                  f.gd[j][3] * (w.gam[j][3] + qv[j][3]) + f.g[j][3] * qdv[j][3]);
+                        const f32x4 ydv = fma4(f.gd[j], gq[j], f.g[j] * qdv[j]);
+                        make_frag(ydf, ydv[0], ydv[1], ydv[2], ydv[3]);
                         mma16(p1d, w.wp[j], ydf);
                     }
                 }
@@ -779,16 +795,19 @@ cnx_fwd_kernel(FwdArgs a) {
                 const uint32_t goff = ok ? (uint32_t)((((int64_t)gy * s + gx) * 16 + 4 * q) * sizeof(T)) : BUF_OOB;
                 float n[4], ov[4];
                 ld4(tile + hoff, n);
+                const f32x4 nv = ld_f32x4(n), ls4 = ld_f32x4(w.ls), sc14 = ld_f32x4(rw.sc1);
+                const f32x4 o4 = fma4(p1, ls4, fma4(sc14, nv, ld_f32x4(rw.sh)));
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ov[i] = p1[i] * w.ls[i] + (rw.sc1[i] * n[i] + rw.sh[i]);
+                for (int i = 0; i < 4; ++i) ov[i] = o4[i];
                 buf_st4(rs_o, goff, ov, (const T*)nullptr);
                 if constexpr (JVP) {
                     float nd[4], scd4[4], shd4[4];
                     ld4(tiled + hoff, nd);
                     ld4(l.fsc + 32 + 4 * q, scd4);
                     ld4(l.fsc + 48 + 4 * q, shd4);
+                    const f32x4 od4 = fma4(p1d, ls4, fma4(sc14, ld_f32x4(nd), fma4(ld_f32x4(scd4), nv, ld_f32x4(shd4))));
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) ov[i] = p1d[i] * w.ls[i] + (rw.sc1[i] * nd[i] + scd4[i] * n[i] + shd4[i]);
+                    for (int i = 0; i < 4; ++i) ov[i] = od4[i];
                     buf_st4(rs_od, goff, ov, (const T*)nullptr);
                 }
             }
@@ -1489,11 +1508,21 @@ inline bool params_ok(const mfc_cnx_params* p) {
            p->con_b && p->ls;
 }
 
-static int64_t MAX_BLOCKS = getenv("MFC_CNX_MAX_BLOCKS") ? atoll(getenv("MFC_CNX_MAX_BLOCKS")) : 2048;
+// Persistent grid per kernel: a multiple of what is resident at once (256 CUs x 4 / 3 / 2 workgroups per CU by
+// registers or LDS), so no partly filled last round; measured at the literal spatial size (tools/bench_cnx.py sweep,
+// 2048 for every kernel before): 4-per-CU kernels 3 rounds (-7..-11 %), the 3-per-CU tangent statistics 3 rounds
+// (-8 %), the 2-per-CU kernels exactly one round (-3..-7 %).  MFC_CNX_MAX_BLOCKS / mfc_cnx_max_blocks override all.
+enum CnxKind { K_STATS = 0, K_APPLY, K_STATS_JVP, K_APPLY_JVP, K_BWD_STATS, K_BWD_MAIN, K_BWD_CONV, K_NKIND };
+static const int64_t DEFAULT_BLOCKS[K_NKIND] = {3072, 3072, 2304, 512, 3072, 512, 512};
+static int64_t MAX_BLOCKS = getenv("MFC_CNX_MAX_BLOCKS") ? atoll(getenv("MFC_CNX_MAX_BLOCKS")) : 0;   // 0: per-kernel defaults
+inline int64_t max_blocks(CnxKind k) { return MAX_BLOCKS > 0 ? MAX_BLOCKS : DEFAULT_BLOCKS[k]; }
 constexpr int MAX_S = 8000;   // one [s, s, 16] fp32 image must stay below the 4 GiB a buffer resource addresses
 
 template <typename K, typename A>
 inline int launch_k(K kern, int64_t grid, size_t lds, hipStream_t st, const A& args) {
+    // MFC_CNX_LDS_PAD (bytes): occupancy probe -- unused extra LDS per workgroup, so fewer workgroups fit a CU
+    static const size_t pad = getenv("MFC_CNX_LDS_PAD") ? (size_t)atoll(getenv("MFC_CNX_LDS_PAD")) : 0;
+    lds += pad;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, args);
     return mfc_launch_status();
@@ -1536,7 +1565,7 @@ int fwd_common(int dtype, int mode, int64_t R, int s, const void* h0, const void
     if (mode == 1 && (!q || !o || (jvp && (!qdot || !odot)))) return MFC_EFAULT;
     FwdArgs a;
     int64_t grid;
-    a.geo = make_geo(R, s, MAX_BLOCKS, grid);
+    a.geo = make_geo(R, s, max_blocks(mode == 0 ? (jvp ? K_STATS_JVP : K_STATS) : (jvp ? K_APPLY_JVP : K_APPLY)), grid);
     a.h0 = h0; a.h0d = h0dot; a.sc = scale; a.sh = shift; a.scd = scaledot; a.shd = shiftdot;
     a.p = to_dev(p); a.S1 = S1; a.S2 = S2; a.q = q; a.qd = qdot; a.o = o; a.od = odot; a.ws = ws;
     static const int dbg = getenv("MFC_CNX_DBG") ? atoi(getenv("MFC_CNX_DBG")) : 0;
@@ -1559,7 +1588,12 @@ extern "C" int mfc_cnx_stats(int dtype, int64_t R, int s, const void* h1, const 
 
 extern "C" int64_t mfc_cnx_ws_elems(int64_t R, int s) {
     if (R <= 0 || s <= 0 || s > MAX_S) return -1;
-    return ws_elems_for(R, s, MAX_BLOCKS);
+    int64_t n = 0;
+    for (int k = 0; k < K_NKIND; ++k) {
+        const int64_t e = ws_elems_for(R, s, max_blocks((CnxKind)k));
+        n = e > n ? e : n;
+    }
+    return n;
 }
 
 extern "C" int mfc_cnx_apply(int dtype, int64_t R, int s, const void* h1, const void* h1dot,
@@ -1601,7 +1635,7 @@ extern "C" int mfc_cnx_bwd_stats(int dtype, int64_t R, int s, const void* h0, co
     if (s > MAX_S) return MFC_ENOSYS;
     BwdArgs a = {};
     int64_t grid;
-    a.geo = make_geo(R, s, MAX_BLOCKS, grid);
+    a.geo = make_geo(R, s, max_blocks(K_BWD_STATS), grid);
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(nullptr);
     a.q = q; a.dout = dout; a.dq = dq; a.ws = ws; a.dbg = BWD_DBG;
     hipStream_t st = (hipStream_t)stream;
@@ -1620,7 +1654,7 @@ extern "C" int mfc_cnx_bwd_main(int dtype, int64_t R, int s, const void* h0, con
     if (s > MAX_S) return MFC_ENOSYS;
     BwdArgs a = {};
     int64_t grid;
-    a.geo = make_geo(R, s, MAX_BLOCKS, grid);
+    a.geo = make_geo(R, s, max_blocks(K_BWD_MAIN), grid);
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(g);
     a.q = q; a.kG = kG; a.dout = dout; a.dc1 = dc1; a.ws = ws; a.dbg = BWD_DBG;
     hipStream_t st = (hipStream_t)stream;
@@ -1644,7 +1678,7 @@ extern "C" int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, con
     if (s > MAX_S) return MFC_ENOSYS;
     BwdArgs a = {};
     int64_t grid;
-    a.geo = make_geo(R, s, MAX_BLOCKS, grid);
+    a.geo = make_geo(R, s, max_blocks(K_BWD_CONV), grid);
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(g);
     a.rho = rho0; a.dc1_in = dc1; a.dout = dout; a.dh0 = dh0; a.dsc = dscale; a.dsh = dshift; a.ws = ws; a.dbg = BWD_DBG;
     hipStream_t st = (hipStream_t)stream;
@@ -1695,6 +1729,6 @@ extern "C" int mfc_ln16_jvp(int dtype, int64_t n_pixels, const void* n, const fl
 
 extern "C" int64_t mfc_cnx_max_blocks(int64_t n) {
     const int64_t old = MAX_BLOCKS;
-    if (n > 0) MAX_BLOCKS = n;
+    if (n >= 0) MAX_BLOCKS = n;      // 0 restores the per-kernel defaults
     return old;
 }

@@ -75,6 +75,32 @@ __device__ inline void gelu_both(float x, float& g, float& dg) {
     g = x * sg;
     dg = sg + g * (1.0f - sg) * da2;
 }
+// The same on four values held as one f32x4 (an MFMA accumulator is one): the plain arithmetic compiles to PACKED f32
+// VALU (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two lanes' worth of f32 per issue slot -- the f32 VALU peak of
+// MI355X_MICROARCH.md is the packed rate), the transcendentals stay scalar.  Probe tools/probe/gelu_rate.hip: 284 vs 366
+// cycles per 8 values.  (Compiler-driven SLP packing of arbitrary scalar code is a different thing and stays off: it
+// pays v_mov shuffles to build register pairs; here the operands already are aligned register quads.)
+__device__ inline f32x4 splat4(float x) { return f32x4{x, x, x, x}; }
+__device__ inline f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ inline f32x4 ld_f32x4(const float* p) { return f32x4{p[0], p[1], p[2], p[3]}; }
+__device__ inline f32x4 gelu_sig4(f32x4 x) {
+    const float c0 = -2.0f * MFC_GELU_K0 * MFC_LOG2E, c1 = c0 * MFC_GELU_K1;
+    const f32x4 t = x * fma4(x * splat4(c1), x, splat4(c0));
+    f32x4 d;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = __builtin_amdgcn_exp2f(t[i]);
+    d = d + splat4(1.0f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = __builtin_amdgcn_rcpf(d[i]);
+    return d;
+}
+__device__ inline f32x4 gelu4(f32x4 x) { return x * gelu_sig4(x); }
+__device__ inline void gelu_both4(f32x4 x, f32x4& g, f32x4& dg) {
+    const f32x4 sg = gelu_sig4(x);
+    const f32x4 da2 = fma4(x * splat4(2.0f * MFC_GELU_K0 * 3.0f * MFC_GELU_K1), x, splat4(2.0f * MFC_GELU_K0));
+    g = x * sg;
+    dg = fma4(g * (splat4(1.0f) - sg), da2, sg);
+}
 // second derivative, needed for d/dx of (t * gelu'(x)) in the tangent's backward
 // (not on the iMF path: the tangent carries no gradient) -- kept out.
 

@@ -26,6 +26,30 @@ __global__ void k(const float* in, float* out, int iters) {
         if (MODE == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float g = gelu_f32(v[j]); acc[j] = __builtin_fmaf(g, g, acc[j]); v[j] += 1e-6f; }
+        } else if (MODE == 2) {
+            // packed f32 VALU (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) for the plain arithmetic, scalar transcendentals
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f2 x = {v[2 * j], v[2 * j + 1]};
+                const f2 c1 = {-2.0f * K0 * K1 * LOG2E, -2.0f * K0 * K1 * LOG2E};
+                const f2 c0 = {-2.0f * K0 * LOG2E, -2.0f * K0 * LOG2E};
+                const f2 one = {1.0f, 1.0f};
+                const f2 t = c1 * x;
+                const f2 u = __builtin_elementwise_fma(x, t, c0);
+                const f2 w = x * u;
+                f2 e;
+                e[0] = __builtin_amdgcn_exp2f(w[0]);
+                e[1] = __builtin_amdgcn_exp2f(w[1]);
+                const f2 d = one + e;
+                f2 rc;
+                rc[0] = __builtin_amdgcn_rcpf(d[0]);
+                rc[1] = __builtin_amdgcn_rcpf(d[1]);
+                const f2 g = x * rc;
+                f2 a2 = {acc[2 * j], acc[2 * j + 1]};
+                a2 = __builtin_elementwise_fma(g, g, a2);
+                acc[2 * j] = a2[0]; acc[2 * j + 1] = a2[1];
+                v[2 * j] += 1e-6f; v[2 * j + 1] += 1e-6f;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -58,11 +82,12 @@ int main() {
     hipMalloc(&din, n * 4); hipMalloc(&dout, n * 4);
     hipMemcpy(din, h.data(), n * 4, hipMemcpyHostToDevice);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 3; ++mode) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(a);
             if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(threads), 0, 0, din, dout, iters);
-            else hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(threads), 0, 0, din, dout, iters);
+            else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(threads), 0, 0, din, dout, iters);
+            else hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(threads), 0, 0, din, dout, iters);
             hipEventRecord(b); hipEventSynchronize(b);
             float ms; hipEventElapsedTime(&ms, a, b);
             // waves per SIMD: blocks*4 waves / 1024 SIMDs = 8 -> per-SIMD iterations = 8 * iters
