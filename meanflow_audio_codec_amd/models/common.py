@@ -43,10 +43,15 @@ def init_from_shapes(shapes: dict, seed: int, device, big_threshold: int = 1 << 
 
 
 def auto_splitk(M: int, N: int, K: int) -> int:
+    """K slices of a product with few output tiles (a pure function of the shape: the slab sums are fixed-order, so
+    results are reproducible).  One or two output tiles (the K = D / K = S products of a ConvFlow block): 512 slices =
+    two workgroups per CU -- measured optimum at K = 392 704 and K = 6 270 016 (tools/sweep_splitk.py: 256..512 slices
+    are 6-12 % faster than 1024, whose 64 MB of slabs per operand-GB start to show, and than 128, which starves HBM)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if K < 2048 or tiles >= 256:
         return 1
-    return max(1, min((K + 255) // 256, (1024 + tiles - 1) // tiles))
+    target = 512 if tiles <= 2 else (1024 + tiles - 1) // tiles
+    return max(1, min((K + 255) // 256, target))
 
 
 def dense(x, w, b=None, *, bias_rows=None, out=None, alpha=1.0, residual=None, beta=1.0):

@@ -28,7 +28,7 @@ def test_algorithmic_bytes():
 def test_symbols_and_traffic_table():
     s = bench.symbol_of("mfc_adamw", (1, 802562048, 3), (True,) * 5)
     assert s == "adamw_vec_kernel<unsigned short, false>"
-    tab = json.loads((pathlib.Path(bench.ROOT) / "profiles" / "r01_final_pmc_traffic.json").read_text())
+    tab = json.loads((pathlib.Path(bench.ROOT) / "profiles" / bench.PMC_TABLE).read_text())
     assert s in tab and tab[s]["avg_hbm_bytes_per_launch"] > 1e9
     assert bench.measured_traffic(s) == tab[s]["avg_hbm_bytes_per_launch"]
     assert bench.symbol_of("mfc_cnx_bwd_main", (1, 128, 626), (True,) * 8) == "cnx_bwd_kernel<unsigned short, 1>"
