@@ -451,6 +451,10 @@ gemm_kernel(GemmArgs g) {
 // holds a primal 16-row tile and the tangent tile of the same samples -- MFC_GEMM_LN16T can apply
 // the tangent of the fused LayerNorm in the same epilogue.
 // ---------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ inline void mma32(f32x4& acc, const s16x8& a, const s16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
 constexpr int NS_BN = 64, NS_K = 128, NS_KS = NS_K / 16, NS_LDR = 80, NS_MAXT = 4;
 struct NsPlan {
     // per wave: up to 4 16-row tiles of C, processed in order; kind 0 = plain, 1 = LN16 primal,
@@ -469,7 +473,7 @@ __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t by
 constexpr uint32_t NS_OOB = 0xFFFFFF00u;
 
 template <int MT>
-__global__ void __launch_bounds__(GT)
+__global__ void __launch_bounds__(GT, MT == 3 ? 3 : 1)      // M = 192 (MT = 3): <= 168 VGPRs = three workgroups per CU
 gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     typedef u16 T;
     typedef Frag<T>::type frag_t;
@@ -483,16 +487,25 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     const int64_t N = g.N;
 
     int mt[MT], kind[MT];
-    frag_t af[MT][NS_KS];
+    // K = 32 MFMA operands (v_mfma_f32_16x16x32_bf16: half the instructions of the K = 16 form for the same matrix-pipe
+    // cycles, i.e. half the time the MFMAs hold the SIMD's issue port).  Which k a (lane, slot) pair carries is free as
+    // long as both operands agree: slots 0-3 = k 32c + 4q .. +3, slots 4-7 = k 32c + 16 + 4q .. +3 -- two K = 16
+    // fragments side by side, so the weight side stays two ds_read_b64_tr_b16 and nothing is shuffled.
+    typedef s16x8 frag8_t;
+    frag8_t af[MT][NS_KS / 2];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         mt[i] = plan.tile[wave][i];
         kind[i] = plan.kind[wave][i];
         const int64_t row = 16 * (int64_t)(mt[i] < 0 ? 0 : mt[i]) + r;
 #pragma unroll
-        for (int c = 0; c < NS_KS; ++c) {
-            if (mt[i] >= 0 && row < g.M) af[i][c] = *reinterpret_cast<const frag_t*>(A + row * g.lda + 16 * c + 4 * q);
-            else af[i][c] = frag_t{0, 0, 0, 0};
+        for (int c = 0; c < NS_KS / 2; ++c) {
+            frag_t lo = frag_t{0, 0, 0, 0}, hi = frag_t{0, 0, 0, 0};
+            if (mt[i] >= 0 && row < g.M) {
+                lo = *reinterpret_cast<const frag_t*>(A + row * g.lda + 32 * c + 4 * q);
+                hi = *reinterpret_cast<const frag_t*>(A + row * g.lda + 32 * c + 16 + 4 * q);
+            }
+            af[i][c] = frag8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
     }
 
@@ -501,23 +514,23 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int c = 0; c < NS_KS; ++c) asm volatile("" ::"v"(af[i][c]));
+        for (int c = 0; c < NS_KS / 2; ++c) asm volatile("" ::"v"(af[i][c]));
 
-    // B tile staging: 128 rows x 8 chunks of 8 columns, 4 chunks per thread; byte offsets are tile-invariant
-    uint32_t boff[4], lds_off[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int ch = threadIdx.x + GT * p, k = ch >> 3, c8 = (ch & 7) * 8;
-        boff[p] = (uint32_t)((k * g.ldb + c8) * 2);
-        lds_off[p] = k * NS_LDR + c8;
-    }
+    // B tile staging: 128 rows x 8 chunks of 8 columns, 4 chunks per thread (k rows 32 apart).  One VGPR offset each for
+    // the global and the LDS side: the other three chunks are reached through the scalar offset of the buffer load and
+    // the immediate offset of the LDS store (six VGPRs less: the M = 192 variant drops from 171 to <= 168 registers,
+    // i.e. from two to three workgroups per CU).
+    const int ch0 = threadIdx.x, k0 = ch0 >> 3, c80 = (ch0 & 7) * 8;
+    const uint32_t boff0 = (uint32_t)((k0 * g.ldb + c80) * 2);
+    const uint32_t bstep = (uint32_t)(32 * g.ldb * 2);          // 256 threads = 32 k rows per chunk index p
+    const int lds_off0 = k0 * NS_LDR + c80;
     u32x4 rb[4];
     auto load_b = [&](int64_t tile) {
         const int64_t n0 = tile * NS_BN;
         // columns >= N of rows < K-1 alias the next row (finite weights, results never stored); the last row is clipped
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(B + n0, (uint32_t)(((NS_K - 1) * g.ldb + (N - n0)) * 2));
 #pragma unroll
-        for (int p = 0; p < 4; ++p) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[p], 0, 0);
+        for (int p = 0; p < 4; ++p) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff0, p * bstep, 0);
     };
 
     // The products are issued TRANSPOSED (C^T tile = B^T A^T: the weight tile is the MFMA A operand, the resident
@@ -535,7 +548,7 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     if (tile < ntiles) {
         load_b(tile);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs + lds_off[p]) = rb[p];
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs + lds_off0 + p * 32 * NS_LDR) = rb[p];
     }
     __syncthreads();
     for (; tile < ntiles; tile += gridDim.x) {
@@ -557,18 +570,20 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < NS_KS; ++c) {
-            frag_t bf[4];
+        for (int c = 0; c < NS_KS / 2; ++c) {
+            frag8_t bf[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                // LDS transpose read: lane 4q'+p of group q supplies k-row 4q+q', columns 16p + 4j .. +3
-                const T* bp = Bs + (16 * c + 4 * q + (r >> 2)) * NS_LDR + 16 * (r & 3) + 4 * j;
-                bf[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
+                // LDS transpose reads: lane 4q'+p of group q supplies k-row 4q+q', columns 16p + 4j .. +3
+                const T* bp = Bs + (32 * c + 4 * q + (r >> 2)) * NS_LDR + 16 * (r & 3) + 4 * j;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp + 16 * NS_LDR));
+                bf[j] = frag8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mma16(acc[i][j], bf[j], af[i][c]);
+                for (int j = 0; j < 4; ++j) mma32(acc[i][j], bf[j], af[i][c]);
         }
         if (threadIdx.x < 16) *reinterpret_cast<u32x4*>(bias_s + 4 * threadIdx.x) = bias_v;
         __syncthreads();   // B tile consumed: the next iteration may overwrite it while slower waves are in the epilogue
@@ -658,7 +673,7 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
         }
         // commit the prefetched B tile (every wave left the MFMA loop at the barrier above)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs + lds_off[p]) = rb[p];
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs + lds_off0 + p * 32 * NS_LDR) = rb[p];
         __syncthreads();
     }
 }
