@@ -1,4 +1,4 @@
-"""CPU (gloo, world_size 2): the data-parallel gradient exchange of meanflow_audio_codec_amd.distributed."""
+"""CPU (gloo, world_size 2 and 4): the data-parallel gradient exchange of meanflow_audio_codec_amd.distributed."""
 import os
 import socket
 
@@ -45,7 +45,13 @@ def _worker(rank, world, port, q):
         blk = {k: v.clone() for k, v in ref.items()}
         red.reduce_tensors(list(blk.values()))
         for k in blk:
-            assert torch.equal(blk[k], grads[k]), k
+            # same sums; bitwise only for two ranks (a ring over more ranks adds in an order that depends on where an
+            # element sits in its bucket, and the two entry points bucket differently)
+            if world == 2:
+                assert torch.equal(blk[k], grads[k]), k
+            else:
+                assert torch.allclose(blk[k].float(), grads[k].float(), rtol=2e-2 if blk[k].dtype == torch.bfloat16 else 1e-5,
+                                      atol=1e-5), k
         assert abs(red.reduce_scalar(loss).item() - total.item()) < 1e-6
         # the two halves of the sharded optimizer's exchange (gloo: emulated with all_reduce / all_gather on views)
         full = torch.arange(8 * world, dtype=torch.float32) * (rank + 1)
@@ -85,8 +91,8 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_grad_reducer_gloo_world2():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_grad_reducer_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -96,7 +102,7 @@ def test_grad_reducer_gloo_world2():
     res = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
 
 
 def test_reducer_requires_process_group():
