@@ -37,7 +37,9 @@ def _fused_step(state, key, x, loss_strategy, row0, global_batch, row_stride=1):
     """Single-GPU schedule: no gradient exchange sits between the reverse pass and the optimizer, so the big kernels
     are updated by the epilogue of their own weight-gradient product (``mfc_gemm_adamw``: the bf16 gradient is never
     written or re-read) and only the remaining leaves go through ``mfc_adamw``.  The fused kernel is bit-identical to
-    gemm -> adamw; whole steps agree with the sequential schedule up to the run-to-run noise of the fp32-atomic sums."""
+    gemm -> adamw, and so are whole steps (every reduction is fixed-order); the one rounding-level difference to the
+    sequential schedule is the bias gradient of a big layer, which the fused kernel sums in its own order when the batch
+    has more than 32 rows."""
     state.begin_update()
     fused = state.fused_updater()
     loss, grads = loss_strategy.compute_loss(state, key, x, row0=row0, global_batch=global_batch, fused=fused,

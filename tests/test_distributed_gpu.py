@@ -62,7 +62,7 @@ def _worker(rank, world, port, q):
             big = sorted(red.sharded)
             assert sum(k.startswith("blocks_") for k in big) == 8 and all(k.endswith("/kernel") for k in big), big
             assert abs(loss - loss_now) < 1e-4 * max(1.0, abs(loss_now))
-            for k in st.work:       # what the kernels read agrees with the all-reduce schedule (atomic-order noise only)
+            for k in st.work:       # what the kernels read agrees with the all-reduce schedule (the all-reduce and the reduce-scatter add the ranks in different orders)
                 d = (st.work[k].float() - ref_now.work[k].float()).abs()
                 assert d.max().item() < 5e-3 and (d > 1e-4).float().mean().item() < 0.05, (k, d.max().item())
             # masters / moments are authoritative on the own slice only ...

@@ -120,12 +120,13 @@ def test_literal_shape_shards_sum_to_global_batch(literal_state):
         if norm == 0:
             continue
         nonzero += 1
-        # bf16 end to end.  Two runs of the SAME batch already differ by 2-3 % of |g|_2 on these +-1 functionals (u by
-        # 0.6 % in norm; tools/noise_probe.py): the 1e-6 order noise of the fp32 atomic reductions flips bf16 roundings,
-        # and after a few of the ~80 rounding stages the difference saturates at one bf16 ulp per element (the same probe
-        # in fp32 storage: 6e-6).  A missing or doubled shard would show as ~50 %.  The tight version of this property
-        # (2e-3, fp32) runs at the small shape in tests/test_conv_flow_gpu.py.
-        assert abs(acc[k] - dot) < 8e-2 * norm, (k, acc[k], dot, norm)
+        # bf16 end to end.  A run is bitwise reproducible (fixed-order reductions), but the full batch and its shards are
+        # different launches: other M -> other tile variants and split-K slice counts -> fp32 sums in another order -> a
+        # few bf16 roundings flip, and after a few of the ~80 rounding stages of the eight blocks the difference saturates
+        # at one bf16 ulp per element (u differs by ~0.6 % in norm, these +-1 functionals by 2-3 % of |g|_2; the same probe
+        # in fp32 storage: 6e-6, tools/noise_probe.py).  A missing or doubled shard would show as ~50 %.  The tight version
+        # of this property (2e-3, fp32) runs at the small shape in tests/test_conv_flow_gpu.py.
+        assert abs(acc[k] - dot) < 6e-2 * norm, (k, acc[k], dot, norm)
     assert nonzero >= 4 * NB
     for k, v in small_full.items():
         scale = v.abs().max().item()
