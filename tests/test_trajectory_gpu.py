@@ -99,12 +99,16 @@ def test_small_shape_five_updates_follow_the_oracle():
     print("small-shape trajectory, unweighted MSE  hip:", [f"{a:.5f}" for a in mse_hip], " oracle:", [f"{a:.5f}" for a in mse_ref])
 
 
-def test_steps_are_bitwise_reproducible():
-    """Fixed-order reductions (split-K slabs, GRN statistic / weight-gradient records, per-example loss sums): the
-    same three bf16 steps from the same state give bit-identical parameters, moments and losses."""
+@pytest.mark.parametrize("B", [5, 40])
+def test_steps_are_bitwise_reproducible(B):
+    """Fixed-order reductions (split-K slabs, GRN statistic / weight-gradient records, per-example loss sums, the bias
+    column sums inside the fused weight-gradient GEMM): the same three bf16 steps from the same state give bit-identical
+    parameters, moments and losses.  B = 40: more than 32 rows, so the fused schedule takes its bias gradients from the
+    GEMM (mfc_gemm_adamw's colsum output) -- reproducible as well, and equal to the sequential schedule's mfc_colsum to
+    rounding only, hence no cross-schedule bitwise check at that batch."""
     from meanflow_audio_codec_amd.models import ConditionalConvFlow, TrainState, adamw
     from meanflow_audio_codec_amd.trainers import ImprovedMeanFlowLoss, PRNGKey, train_step
-    D, CD, LAT, NB, B = 2496, 128, 24, 2, 5         # s = 49: ragged tiles, several tiles per workgroup range
+    D, CD, LAT, NB = 2496, 128, 24, 2               # s = 49: ragged tiles, several tiles per workgroup range
     runs = []
     for rep in range(2):
         for fuse in (True, False):
@@ -126,9 +130,12 @@ def test_steps_are_bitwise_reproducible():
             assert torch.equal(a[2][k], b[2][k]) and torch.equal(a[3][k], b[3][k]), (fuse, k)
     # the fused schedule (AdamW in the weight-gradient GEMM's epilogue) is bit-identical to gemm -> adamw as well
     f, u = [r for r in runs if r[0]][0], [r for r in runs if not r[0]][0]
-    assert f[1] == u[1]
-    for k in f[2]:
-        assert torch.equal(f[2][k], u[2][k]), k
+    if B <= 32:
+        assert f[1] == u[1]
+        for k in f[2]:
+            assert torch.equal(f[2][k], u[2][k]), k
+    else:
+        assert max(abs(a - b) for a, b in zip(f[1], u[1])) < 1e-3
 
 
 def test_ci_shape_oracle_parity_and_trajectory():
