@@ -375,6 +375,11 @@ __host__ __device__ inline size_t lds2_bytes(int ntile, bool ws) {
     b = (b + 15) & ~(size_t)15;
     return b + 64 * sizeof(float) + 2 * TH * TW * sizeof(float);
 }
+// cnx_bwd_conv_kernel: two double-buffered halo tiles, one compact 16 x 16 dout tile, two 16 x 16 tiles of 1/sigma
+template <typename T>
+__host__ __device__ inline size_t lds_bwd_conv_bytes() {
+    return (size_t)Halo<T>::ELEMS * sizeof(T) * 4 + (size_t)TH * TW * 16 * sizeof(T) + 2 * TH * TW * sizeof(float);
+}
 template <typename T>
 __device__ inline Lds2<T> carve2(unsigned char* base, int ntile, bool ws, int wave) {
     Lds2<T> l;
@@ -1135,7 +1140,15 @@ cnx_bwd_conv_kernel(BwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, m = lane & 15;
-    Lds2<T> l = carve2<T>(smem, 3, false, wave);   // tile 0: h1 halo, tile 1: dc1 halo, tile 2: dout (+ the rho tile)
+    // LDS: h1 and dc1 halo tiles (double-buffered DMA), then dout and 1/sigma of the tile's own 16 x 16 pixels.  dout needs
+    // no halo and no second buffer: every wave DMA-writes exactly the four rows it reads itself, so it takes its rows
+    // into registers at the top of a tile and requests the next tile's rows into the same place -- 51.7 KB per workgroup
+    // instead of 69 KB, i.e. three workgroups per CU instead of two (this kernel is the one close to its HBM bound).
+    Lds2<T> l = carve2<T>(smem, 2, false, wave);   // tile 0: h1 halo, tile 1: dc1 halo
+    T* const dout_c = l.tile0 + 4 * Halo<T>::ELEMS;                       // [TH][CPP][TW] 16-byte chunks
+    const uint32_t dout_addr = l.tile0_addr + 4 * (uint32_t)(Halo<T>::ELEMS * sizeof(T));
+    l.rho = reinterpret_cast<float*>(dout_c + TH * TW * 16);
+    l.rho_addr = dout_addr + (uint32_t)(TH * TW * 16 * sizeof(T));
     const T* cw = (const T*)a.p.conv_w;  // [tap][ic][oc]
     frag_t wcT[9];  // A[row=ic][k=oc] of the transposed product dh2^T = Wc dc1^T
 #pragma unroll
@@ -1208,10 +1221,25 @@ cnx_bwd_conv_kernel(BwdArgs a) {
         const uint32_t lds_addr = dst + wave * 256;
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(gp), "s"(lds_addr) : "memory", "m0");
     };
+    // dout rows RPW*wave .. +RPW-1 of the tile: CPP DMA instructions per wave, chunk slot = 64 i + lane of the wave's
+    // [RPW][CPP][TW] region (the layout the row loop reads: 16 consecutive pixels of one chunk index are contiguous)
+    constexpr int DCPP = Halo<T>::CPP, DEPC = Halo<T>::EPC;
+    auto request_dout = [&](const TileCoord& c) {
+#pragma unroll
+        for (int i = 0; i < DCPP; ++i) {
+            const int slot = i * 64 + lane, yl = slot / (DCPP * TW), rem = slot - yl * (DCPP * TW);
+            const int part = rem / TW, px = rem - part * TW;
+            const int gy = c.y0 + wave * RPW + yl, gxx = c.x0 + px;
+            const T* gp = (gy < s && gxx < s) ? doutp + c.r * img + ((int64_t)gy * s + gxx) * 16 + part * DEPC
+                                              : reinterpret_cast<const T*>(&g_zero16);
+            const uint32_t lds_addr = dout_addr + (uint32_t)((wave * DCPP + i) * 1024);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gp), "s"(lds_addr) : "memory", "m0");
+        }
+    };
     auto request_all = [&](int b, const TileCoord& c) {
         hl.request(l.tile_addr(0, b), h0 + c.r * img, s, c.y0, c.x0, wave);
         hl.request(l.tile_addr(1, b), dc1 + c.r * img, s, c.y0, c.x0, wave);
-        hl.request(l.tile_addr(2, b), doutp + c.r * img, s, c.y0, c.x0, wave);
+        request_dout(c);
         request_rho(l.rho_addr + b * (uint32_t)(TH * TW * sizeof(float)), c);
     };
     TileCoord tnext = tile_coord(a.geo, t0 < t1 ? t0 : 0);
@@ -1238,12 +1266,19 @@ cnx_bwd_conv_kernel(BwdArgs a) {
             for (int i = 0; i < 4; ++i) { land(sc1[i]); land(shr[i]); }
             rs_dh = make_rsrc((const T*)a.dh0 + r * img, (uint32_t)(img * sizeof(T)));
         }
+        // this wave's RPW rows of dout (zero outside the image), taken before the next tile's rows replace them
+        frag_t dor[RPW];
+#pragma unroll
+        for (int ri = 0; ri < RPW; ++ri) {
+            const int cq = (4 * q) / DEPC, wq = (4 * q) % DEPC;
+            dor[ri] = *reinterpret_cast<const frag_t*>(dout_c + (((wave * RPW + ri) * DCPP + cq) * TW + m) * DEPC + wq);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < t1) request_all(cur ^ 1, tnext);
         __builtin_amdgcn_sched_barrier(0);
         const T* tile = l.tile(0, cur);
         const T* dtile = l.tile(1, cur);
-        const T* dotile = l.tile(2, cur);
         const float* rtile = l.rho + cur * (TH * TW);
         const bool border = tile_on_border(s, y0, x0);
 #pragma unroll 1
@@ -1252,7 +1287,8 @@ cnx_bwd_conv_kernel(BwdArgs a) {
             const int gy = y0 + y;
             const bool ok = gy < s && gx < s;
             float dov[4];
-            ld4(dotile + Halo<T>::off(y + 1, m + 1, q), dov);   // zero outside the image
+            static_assert(RPW == 4, "row select below");
+            unfrag(ri == 0 ? dor[0] : ri == 1 ? dor[1] : ri == 2 ? dor[2] : dor[3], dov);   // (ri is wave-uniform)
             const float rho = rtile[y * TW + m];
             // dh2 = conv^T(dc1): h2[p] feeds c1[p - (i-1, j-1)] through K[i][j]
             f32x4 dh = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1511,9 +1547,10 @@ inline bool params_ok(const mfc_cnx_params* p) {
 // Persistent grid per kernel: a multiple of what is resident at once (256 CUs x 4 / 3 / 2 workgroups per CU by
 // registers or LDS), so no partly filled last round; measured at the literal spatial size (tools/bench_cnx.py sweep,
 // 2048 for every kernel before): 4-per-CU kernels 3 rounds (-7..-11 %), the 3-per-CU tangent statistics 3 rounds
-// (-8 %), the 2-per-CU kernels exactly one round (-3..-7 %).  MFC_CNX_MAX_BLOCKS / mfc_cnx_max_blocks override all.
+// (-8 %), the 2-per-CU kernels exactly one round (-3..-7 %); the conv-gradient kernel, three per CU since its dout
+// tile became compact and single-buffered, one round of 768 (-7 % against two per CU).  MFC_CNX_MAX_BLOCKS / mfc_cnx_max_blocks override all.
 enum CnxKind { K_STATS = 0, K_APPLY, K_STATS_JVP, K_APPLY_JVP, K_BWD_STATS, K_BWD_MAIN, K_BWD_CONV, K_NKIND };
-static const int64_t DEFAULT_BLOCKS[K_NKIND] = {3072, 3072, 2304, 512, 3072, 512, 512};
+static const int64_t DEFAULT_BLOCKS[K_NKIND] = {3072, 3072, 2304, 512, 3072, 512, 768};
 static int64_t MAX_BLOCKS = getenv("MFC_CNX_MAX_BLOCKS") ? atoll(getenv("MFC_CNX_MAX_BLOCKS")) : 0;   // 0: per-kernel defaults
 inline int64_t max_blocks(CnxKind k) { return MAX_BLOCKS > 0 ? MAX_BLOCKS : DEFAULT_BLOCKS[k]; }
 constexpr int MAX_S = 8000;   // one [s, s, 16] fp32 image must stay below the 4 GiB a buffer resource addresses
@@ -1682,8 +1719,8 @@ extern "C" int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, con
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(g);
     a.rho = rho0; a.dc1_in = dc1; a.dout = dout; a.dh0 = dh0; a.dsc = dscale; a.dsh = dshift; a.ws = ws; a.dbg = BWD_DBG;
     hipStream_t st = (hipStream_t)stream;
-    int rc = dtype == MFC_F32 ? launch_k(cnx_bwd_conv_kernel<float>, grid, lds2_bytes<float>(3, false), st, a)
-                              : launch_k(cnx_bwd_conv_kernel<u16>, grid, lds2_bytes<u16>(3, false), st, a);
+    int rc = dtype == MFC_F32 ? launch_k(cnx_bwd_conv_kernel<float>, grid, lds_bwd_conv_bytes<float>(), st, a)
+                              : launch_k(cnx_bwd_conv_kernel<u16>, grid, lds_bwd_conv_bytes<u16>(), st, a);
     if (!rc) rc = reduce_rows(ws, a.geo, REC_CONV, 9 * 256, 32, 16, dscale, dshift, st);
     if (!rc) {
         RedSegs sg = {{{g->conv_w, 0, 9 * 256}, {nullptr, 0, 0}, {nullptr, 0, 0}, {nullptr, 0, 0}}, 1};

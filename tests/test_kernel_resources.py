@@ -33,7 +33,8 @@ def test_no_vector_spills_and_no_scratch_in_bf16_kernels(res):
 @pytest.mark.parametrize("kernel,max_vgpr", [
     ("cnx_fwd_kernel<unsigned short, false, 0>", 128), ("cnx_fwd_kernel<unsigned short, false, 1>", 128),
     ("cnx_bwd_kernel<unsigned short, 0>", 128), ("cnx_fwd_kernel<unsigned short, true, 0>", 168),
-    ("cnx_bwd_conv_kernel<unsigned short>", 168), ("cnx_fwd_kernel<unsigned short, true, 1>", 256),
+    ("cnx_bwd_conv_kernel<unsigned short>", 168),      # + 51.7 KB of LDS: three workgroups per CU
+    ("cnx_fwd_kernel<unsigned short, true, 1>", 256),
     ("cnx_bwd_kernel<unsigned short, 1>", 256),
     ("gemm_kernel<unsigned short, 64, true, false, 128>", 168),     # weight gradient + fused AdamW (the dominant kernel)
     ("gemm_kernel<unsigned short, 64, false, true, 128>", 168),
