@@ -880,7 +880,8 @@ cnx_bwd_kernel(BwdArgs a) {
     const T* h0 = (const T*)a.h0;
     Halo<T> hl;
     hl.init(s, wave, lane);
-    RowW<T, false> rw;
+    constexpr bool BK32 = MODE == 1;   // K = 32 conv steps where registers are not what limits occupancy (MODE 0 sits at 122 of 128)
+    RowW<T, false, BK32> rw;
     // VMEM instructions between a DMA request and its wait.  MODE 0 prefetches dout through registers (RPW buffer
     // loads; it has no stores, so the compiler's own wait for them drains nothing, and a second DMA tile would cost
     // a workgroup per CU in LDS).  MODE 1 takes dout as a second DMA tile: with a register prefetch the compiler
@@ -995,7 +996,7 @@ cnx_bwd_kernel(BwdArgs a) {
                 ld4(dotile + Halo<T>::off(y + 1, m + 1, q), dov);          // zero outside the image
             }
             RowFwd<T, false> f;
-            chain_row<T, false, MODE == 1>(tile, nullptr, l.wc0, w, rw, border, gy, gx, s, y, q, m, lane, f);
+            chain_row<T, false, MODE == 1, BK32>(tile, nullptr, l.wc0, w, rw, border, gy, gx, s, y, q, m, lane, f);
             float dp1[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) dp1[i] = dov[i] * w.ls[i];
