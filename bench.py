@@ -132,8 +132,9 @@ def symbol_of(name, ints, nn):
         dt, flags, M, N, K = ints[:5]
         T = "float" if dt == 0 else "unsigned short"
         tf = lambda b: "true" if b else "false"
-        if dt == 1 and not (flags & 3) and K == 128 and M <= 256 and not (flags & 8):
-            return f"gemm_nstream_kernel<{(((M + 15) // 16) + 3) // 4}>"   # 16-row tiles per wave
+        if dt == 1 and not (flags & 1) and K == 128 and M <= 256 and not (flags & 8):
+            # A in registers, B streamed: NN (forward products) or NT (dX against a [N, 128] kernel; no bias / LayerNorm)
+            return f"gemm_nstream_kernel<{(((M + 15) // 16) + 3) // 4}, {tf(flags & 2)}>"   # 16-row tiles per wave
         return f"gemm_kernel<{T}, {32 if K <= 32 else 64}, {tf(flags & 1)}, {tf(flags & 2)}, {128 if M > 64 else 64}>"
     if name.startswith("mfc_cnx_"):
         T = "float" if ints[0] == 0 else "unsigned short"

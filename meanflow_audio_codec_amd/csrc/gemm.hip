@@ -472,12 +472,17 @@ __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t by
 }
 constexpr uint32_t NS_OOB = 0xFFFFFF00u;
 
-template <int MT>
+// NT = false: B is [K, N] row-major (the forward products: 128-byte row segments of 128 weight rows per tile, read back
+// with LDS transpose reads).  NT = true: B is [N, K] row-major (the dX products against a [S, 128] / [D, 128] kernel): a
+// tile is 64 consecutive rows of 256 bytes = one contiguous 16 KB burst, kept as [n][k] in LDS and read with plain
+// ds_read_b128.
+template <int MT, bool NT>
 __global__ void __launch_bounds__(GT, MT == 3 ? 3 : 1)      // M = 192 (MT = 3): <= 168 VGPRs = three workgroups per CU
 gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     typedef u16 T;
     typedef Frag<T>::type frag_t;
-    __shared__ __attribute__((aligned(16))) T Bs[NS_K * NS_LDR];
+    constexpr int NS_LDN = NS_K + 8;        // NT: [64 n][128 k] rows padded by 16 bytes
+    __shared__ __attribute__((aligned(16))) T Bs[NT ? NS_BN * NS_LDN : NS_K * NS_LDR];
     __shared__ __attribute__((aligned(16))) float bias_s[NS_BN];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -500,12 +505,17 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
         const int64_t row = 16 * (int64_t)(mt[i] < 0 ? 0 : mt[i]) + r;
 #pragma unroll
         for (int c = 0; c < NS_KS / 2; ++c) {
-            frag_t lo = frag_t{0, 0, 0, 0}, hi = frag_t{0, 0, 0, 0};
-            if (mt[i] >= 0 && row < g.M) {
-                lo = *reinterpret_cast<const frag_t*>(A + row * g.lda + 32 * c + 4 * q);
-                hi = *reinterpret_cast<const frag_t*>(A + row * g.lda + 32 * c + 16 + 4 * q);
+            if constexpr (NT) {      // k of a (lane, slot): 32c + 8q + slot on both operands (one 16-byte piece each)
+                af[i][c] = frag8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                if (mt[i] >= 0 && row < g.M) af[i][c] = *reinterpret_cast<const frag8_t*>(A + row * g.lda + 32 * c + 8 * q);
+            } else {
+                frag_t lo = frag_t{0, 0, 0, 0}, hi = frag_t{0, 0, 0, 0};
+                if (mt[i] >= 0 && row < g.M) {
+                    lo = *reinterpret_cast<const frag_t*>(A + row * g.lda + 32 * c + 4 * q);
+                    hi = *reinterpret_cast<const frag_t*>(A + row * g.lda + 32 * c + 16 + 4 * q);
+                }
+                af[i][c] = frag8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
-            af[i][c] = frag8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
     }
 
@@ -520,15 +530,19 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     // the global and the LDS side: the other three chunks are reached through the scalar offset of the buffer load and
     // the immediate offset of the LDS store (six VGPRs less: the M = 192 variant drops from 171 to <= 168 registers,
     // i.e. from two to three workgroups per CU).
-    const int ch0 = threadIdx.x, k0 = ch0 >> 3, c80 = (ch0 & 7) * 8;
+    const int ch0 = threadIdx.x;
+    const int k0 = NT ? (ch0 >> 4) : (ch0 >> 3), c80 = NT ? (ch0 & 15) * 8 : (ch0 & 7) * 8;   // NT: k0 = the tile row n
     const uint32_t boff0 = (uint32_t)((k0 * g.ldb + c80) * 2);
-    const uint32_t bstep = (uint32_t)(32 * g.ldb * 2);          // 256 threads = 32 k rows per chunk index p
-    const int lds_off0 = k0 * NS_LDR + c80;
+    const uint32_t bstep = (uint32_t)((NT ? 16 : 32) * g.ldb * 2);          // rows per chunk index p: 256 threads / chunks per row
+    constexpr int LDS_PSTEP = NT ? 16 * NS_LDN : 32 * NS_LDR;
+    const int lds_off0 = k0 * (NT ? NS_LDN : NS_LDR) + c80;
     u32x4 rb[4];
     auto load_b = [&](int64_t tile) {
         const int64_t n0 = tile * NS_BN;
-        // columns >= N of rows < K-1 alias the next row (finite weights, results never stored); the last row is clipped
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(B + n0, (uint32_t)(((NS_K - 1) * g.ldb + (N - n0)) * 2));
+        // NN: columns >= N of rows < K-1 alias the next row (finite weights, results never stored); the last row is clipped.
+        // NT: rows >= N are past the end of the resource (zeros).
+        const __amdgpu_buffer_rsrc_t rs = NT ? make_rsrc(B + n0 * g.ldb, (uint32_t)(((N - n0 < NS_BN ? N - n0 : NS_BN) - 1) * g.ldb + NS_K) * 2)
+                                             : make_rsrc(B + n0, (uint32_t)(((NS_K - 1) * g.ldb + (N - n0)) * 2));
 #pragma unroll
         for (int p = 0; p < 4; ++p) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff0, p * bstep, 0);
     };
@@ -548,7 +562,7 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     if (tile < ntiles) {
         load_b(tile);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs + lds_off0 + p * 32 * NS_LDR) = rb[p];
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs + lds_off0 + p * LDS_PSTEP) = rb[p];
     }
     __syncthreads();
     for (; tile < ntiles; tile += gridDim.x) {
@@ -574,11 +588,17 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
             frag8_t bf[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                // LDS transpose reads: lane 4q'+p of group q supplies k-row 4q+q', columns 16p + 4j .. +3
-                const T* bp = Bs + (32 * c + 4 * q + (r >> 2)) * NS_LDR + 16 * (r & 3) + 4 * j;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp + 16 * NS_LDR));
-                bf[j] = frag8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if constexpr (NT) {
+                    // MFMA row rho = r of n-tile j is tile column 16 (r >> 2) + 4 j + (r & 3) (see below): that row of the
+                    // [n][k] image, k = 32c + 8q .. +7
+                    bf[j] = *reinterpret_cast<const frag8_t*>(Bs + (16 * (r >> 2) + 4 * j + (r & 3)) * NS_LDN + 32 * c + 8 * q);
+                } else {
+                    // LDS transpose reads: lane 4q'+p of group q supplies k-row 4q+q', columns 16p + 4j .. +3
+                    const T* bp = Bs + (32 * c + 4 * q + (r >> 2)) * NS_LDR + 16 * (r & 3) + 4 * j;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp + 16 * NS_LDR));
+                    bf[j] = frag8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -673,7 +693,7 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
         }
         // commit the prefetched B tile (every wave left the MFMA loop at the barrier above)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs + lds_off0 + p * 32 * NS_LDR) = rb[p];
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs + lds_off0 + p * LDS_PSTEP) = rb[p];
         __syncthreads();
     }
 }
@@ -953,20 +973,25 @@ int gemm_impl(int dtype, int flags, int64_t M, int64_t N, int64_t K, const void*
     const bool ln = g.ln_rstd != nullptr, ln_tan = ln && (flags & MFC_GEMM_LN16T) && bias_rows < M;
     if (ln_tan && M - bias_rows > bias_rows) return MFC_EINVAL;
     g.m_base = 0;
-    // skinny NN products with the whole A operand in registers
-    if (dtype == MFC_BF16 && !opt && !ta && !tb && K == NS_K && !use_ws && g.vecA && g.vecB && g.vecC && !ns_disabled() &&
-        ldb < (1 << 23) && ldc < (1 << 26) && (!R || ldr < (1 << 26)) && N < (1LL << 29)) {   // 32-bit buffer offsets
+    // skinny NN / NT products (K = 128) with the whole A operand in registers
+    if (dtype == MFC_BF16 && !opt && !ta && K == NS_K && !use_ws && g.vecA && g.vecB && g.vecC && !ns_disabled() &&
+        (tb ? (ldb == NS_K && !ln && !bias && N * (int64_t)NS_K * 2 < (1LL << 32)) : ldb < (1 << 23)) &&
+        ldc < (1 << 26) && (!R || ldr < (1 << 26)) && N < (1LL << 29)) {   // 32-bit buffer offsets
         NsPlan plan;
         const int mt = ns_make_plan(M, bias_rows, ln, ln_tan, plan);
         if (mt > 0) {
             const int64_t ntiles = ceil_div64(N, NS_BN);
             int64_t grid = ntiles < ns_max_blocks() ? ntiles : ns_max_blocks();
+#define MFC_NS_LAUNCH(MTV)                                                                                                      \
+            if (tb) hipLaunchKernelGGL((gemm_nstream_kernel<MTV, true>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles);   \
+            else hipLaunchKernelGGL((gemm_nstream_kernel<MTV, false>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles)
             switch (mt) {
-                case 1: hipLaunchKernelGGL((gemm_nstream_kernel<1>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles); break;
-                case 2: hipLaunchKernelGGL((gemm_nstream_kernel<2>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles); break;
-                case 3: hipLaunchKernelGGL((gemm_nstream_kernel<3>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles); break;
-                default: hipLaunchKernelGGL((gemm_nstream_kernel<4>), dim3((unsigned)grid), dim3(GT), 0, st, g, plan, ntiles); break;
+                case 1: MFC_NS_LAUNCH(1); break;
+                case 2: MFC_NS_LAUNCH(2); break;
+                case 3: MFC_NS_LAUNCH(3); break;
+                default: MFC_NS_LAUNCH(4); break;
             }
+#undef MFC_NS_LAUNCH
             return mfc_launch_status();
         }
     }

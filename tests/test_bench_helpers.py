@@ -33,4 +33,4 @@ def test_symbols_and_traffic_table():
     assert bench.measured_traffic(s) == tab[s]["avg_hbm_bytes_per_launch"]
     assert bench.symbol_of("mfc_cnx_bwd_main", (1, 128, 626), (True,) * 8) == "cnx_bwd_kernel<unsigned short, 1>"
     assert bench.symbol_of("mfc_gemm", (0, 3, 4, 4, 16) + (0,) * 7, ()) == "gemm_kernel<float, 32, true, true, 64>"
-    assert bench.symbol_of("mfc_gemm", (1, 16, 192, 6270016, 128) + (0,) * 7, ()) == "gemm_nstream_kernel<3>"
+    assert bench.symbol_of("mfc_gemm", (1, 16, 192, 6270016, 128) + (0,) * 7, ()) == "gemm_nstream_kernel<3, false>"

@@ -40,7 +40,7 @@ def test_no_vector_spills_and_no_scratch_in_bf16_kernels(res):
     ("gemm_kernel<unsigned short, 64, false, true, 128>", 168),
     ("gemm_kernel<unsigned short, 64, false, false, 64>", 128), ("gemm_kernel<unsigned short, 64, true, false, 64>", 128),
     ("gemm_kernel<unsigned short, 64, false, false, 192>", 256),
-    ("gemm_nstream_kernel<3>", 256), ("gemm_nstream_kernel<1>", 128),
+    ("gemm_nstream_kernel<3, false>", 256), ("gemm_nstream_kernel<1, false>", 128), ("gemm_nstream_kernel<2, true>", 168),
     ("m512::mdct512_fwd_kernel<true, 5>", 128), ("m512::mdct512_inv_kernel<true>", 168),
 ])
 def test_occupancy_tier_of_the_hot_kernels(res, kernel, max_vgpr):
