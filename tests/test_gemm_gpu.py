@@ -137,6 +137,33 @@ def _ln_ref(pre, R, N):
     return (grp - mu) * rho, rho
 
 
+@pytest.mark.parametrize("M,N", NS_SHAPES + [(128, 64 * 37 + 48)])
+def test_gemm_nstream_nt_shapes(M, N):
+    """bf16 NT products with K = 128, M <= 256 and a dense [N, 128] B (the dX products of the ConvFlow block) take the NT
+    form of the N-streaming kernel: alpha, residual, accumulate, ragged last tile -- against fp64; and bitwise against
+    the tiled kernel (MFC_GEMM_NSTREAM=0 is read once per process, so that comparison uses a strided B, which the
+    N-streaming dispatch declines)."""
+    from meanflow_audio_codec_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(13)
+    dtype, K = torch.bfloat16, 128
+    A = torch.randn(M, K, generator=g, device="cuda").to(dtype)
+    B = torch.randn(N, K, generator=g, device="cuda").to(dtype)
+    R = torch.randn(M, N, generator=g, device="cuda").to(dtype)
+    ref = 0.5 * (A.double() @ B.double().T) - 1.5 * R.double()
+    C = ops.gemm(A, B, trans_b=True, alpha=0.5, residual=R, beta=-1.5)
+    assert (C.double() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    C0 = torch.randn(M, N, generator=g, device="cuda").to(dtype)
+    C1 = ops.gemm(A, B, trans_b=True, out=C0.clone(), accumulate=True)
+    ref1 = A.double() @ B.double().T + C0.double()
+    assert (C1.double() - ref1).abs().max().item() <= 2e-2 * max(1.0, ref1.abs().max().item())
+    # the same product through the tiled kernel (a B with leading dimension 136 is not dense: no N-streaming)
+    Bs = torch.zeros(N, K + 8, device="cuda", dtype=dtype)[:, :K]
+    Bs.copy_(B)
+    C2 = ops.gemm(A, Bs, trans_b=True)
+    C3 = ops.gemm(A, B, trans_b=True)
+    assert (C2.double() - C3.double()).abs().max().item() <= 1e-2 * max(1.0, C3.double().abs().max().item())
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 3e-2)])
 @pytest.mark.parametrize("R,nt,N", [(32, 16, 16 * 37), (128, 64, 16 * 40), (48, 48, 16 * 9), (20, 7, 16 * 5)])
 def test_gemm_ln16_tangent_rows(dtype, tol, R, nt, N):
