@@ -63,6 +63,29 @@ def test_nstream_forward_products_at_literal_width(N):
     print(f"N-streaming product N={N}: worst chunk error {worst:.3e}")
 
 
+@pytest.mark.parametrize("N,res", [(S, False), (D, True)])
+def test_nstream_dx_products_at_literal_width(N, res):
+    """[128, 128] x [N, 128]^T bf16 (dX of output_proj1, N = S; dX of input_proj1 with its residual, N = D): the NT form of
+    the N-streaming kernel -- 64-row weight tiles addressed through 32-bit buffer offsets up to N * 256 bytes = 1.6 GB."""
+    from meanflow_audio_codec_amd import ops
+    _need(30)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    M = 128
+    dA = torch.randn(M, K128, generator=g, device="cuda").bfloat16()
+    W = (torch.randn(N, K128, generator=g, device="cuda") / 8).bfloat16()
+    Rres = torch.randn(M, N, generator=g, device="cuda").bfloat16() if res else None
+    C = ops.gemm(dA, W, trans_b=True, residual=Rres, beta=1.0) if res else ops.gemm(dA, W, trans_b=True)
+    worst = 0.0
+    for lo, hi in _chunks(N, 16 * 16384):
+        ref = dA.float() @ W[lo:hi].float().T
+        if res:
+            ref = ref + Rres[:, lo:hi].float()
+        err = (C[:, lo:hi].float() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+        worst = max(worst, err)
+        assert err <= 2e-2, (lo, hi, err)
+    print(f"N-streaming NT product N={N}: worst chunk error {worst:.3e}")
+
+
 @pytest.mark.parametrize("M", [192, 64])
 def test_split_k_product_at_literal_depth(M):
     """[M, S] x [S, 128] bf16 (output_proj1 of every block): K = 6 270 016 split over hundreds of workgroup slices whose
