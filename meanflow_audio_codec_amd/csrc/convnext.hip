@@ -345,6 +345,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ inline void mma32(f32x4& acc, const s16x8& a, const s16x8& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
+// The 32 -> 16 contraction of the ConvNeXt block as ONE K = 32 step (bf16): the two K = 16 operand fragments of the
+// expanded channels 0-15 / 16-31 side by side -- which k a (lane, slot) pair carries is free as long as both operands
+// agree.  Same matrix-pipe cycles as two K = 16 steps, one issue slot less.  (No accumulator chain mixes shapes here:
+// the accumulator starts from the bias registers.)  Used in the reverse kernel (-3 %); in the forward apply kernels,
+// whose other MFMAs are K = 16, it measured 1-2 % slower.
+__device__ inline void mma_pair(f32x4& acc, const s16x4& a0, const s16x4& a1, const s16x4& b0, const s16x4& b1) {
+    mma32(acc, s16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]},
+          s16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]});
+}
+__device__ inline void mma_pair(f32x4& acc, const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1) {
+    mma16(acc, a0, b0);      // fp32 storage: the exact f32 MFMA chain, as before
+    mma16(acc, a1, b1);
+}
 __device__ inline s16x8 pack8(const float v[8]) {
     typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
     return __builtin_bit_cast(s16x8, u32x4_{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
@@ -1023,8 +1036,8 @@ cnx_bwd_kernel(BwdArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) yv[j][i] = f.g[j][i] * (w.gam[j][i] + qv[j][i]) + w.bet[j][i];
                     make_frag(yf[j], yv[j][0], yv[j][1], yv[j][2], yv[j][3]);
-                    mma16(p1, w.wp[j], yf[j]);
                 }
+                mma_pair(p1, w.wp[0], w.wp[1], yf[0], yf[1]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dls[i] += dov[i] * p1[i];
                 // d gelu / d expand
@@ -1040,8 +1053,8 @@ cnx_bwd_kernel(BwdArgs a) {
                         dbe[j][i] += de[i];
                     }
                     make_frag(def[j], de[0], de[1], de[2], de[3]);
-                    mma16(dn1, weT[j], def[j]);      // dn1^T = We de^T
                 }
+                mma_pair(dn1, weT[0], weT[1], def[0], def[1]);      // dn1^T = We de^T
                 float dn[4] = {dn1[0], dn1[1], dn1[2], dn1[3]}, dc[4];
                 ln_bwd_a(dn, f.n1, f.rho1, dc);
                 buf_st4(rs_dc, ok ? (uint32_t)((((int64_t)gy * s + gx) * 16 + 4 * q) * sizeof(T)) : BUF_OOB, dc, (const T*)nullptr);
