@@ -34,3 +34,15 @@ def test_symbols_and_traffic_table():
     assert bench.symbol_of("mfc_cnx_bwd_main", (1, 128, 626), (True,) * 8) == "cnx_bwd_kernel<unsigned short, 1>"
     assert bench.symbol_of("mfc_gemm", (0, 3, 4, 4, 16) + (0,) * 7, ()) == "gemm_kernel<float, 32, true, true, 64>"
     assert bench.symbol_of("mfc_gemm", (1, 16, 192, 6270016, 128) + (0,) * 7, ()) == "gemm_nstream_kernel<3, false>"
+
+
+def test_auto_splitk_is_a_pure_function_of_the_shape():
+    """models/common.py::auto_splitk: the slab count decides the (fixed) summation order of a split-K product, so it
+    must depend on the shape only; one- and two-tile outputs take the measured optimum of 512 slices."""
+    from meanflow_audio_codec_amd.models.common import auto_splitk
+    S, D = 6270016, 392704
+    assert auto_splitk(128, 128, S) == 512 and auto_splitk(192, 128, S) == 512 and auto_splitk(64, 128, D) == 512
+    assert auto_splitk(128, 128, 1000) == 1                      # short K: no split
+    assert auto_splitk(128, 128, 4096) == 16                     # never more slices than 256-deep chunks
+    assert auto_splitk(128, S, 128) == 1 and auto_splitk(4096, 8192, 100000) == 1   # plenty of output tiles already
+    assert auto_splitk(384, 128, S) == (1024 + 2) // 3          # three tiles: ~1024 workgroups in total
