@@ -39,8 +39,9 @@ extern "C" {
 
 /* library / ABI version and a one-line description of the build.  Version 2 (round 2): row_stride / data_size arguments
  * of mfc_sample_tr and mfc_flow_prepare, caller-owned workspaces instead of atomics (mfc_gemm_ws_elems,
- * mfc_cnx_ws_elems, MFC_FLOW_LOSS_WS_PER_ROW), colsum output of mfc_gemm_adamw. */
-#define MFC_ABI_VERSION 2
+ * mfc_cnx_ws_elems, MFC_FLOW_LOSS_WS_PER_ROW), colsum output of mfc_gemm_adamw.  Version 3 (round 3): additions only --
+ * mfc_randn_dev (noise draw as a graph node). */
+#define MFC_ABI_VERSION 3
 int mfc_abi_version(void);
 const char* mfc_build_info(void);
 
@@ -267,6 +268,12 @@ int mfc_flow_prepare(int dtype, int64_t B, int64_t D, const float* x, const floa
  * (evaluators/sampling.py:50). */
 int mfc_randn(uint64_t seed, uint64_t stream_id, int64_t row0, int64_t B, int64_t D, float* out,
               void* stream);
+/* The same draw as a FIXED graph node (evaluators/sampling.py:50 inside the captured decoder): the first global row is
+ * read from device memory (*row0_dev), the result is written in `dtype` [B,D], and *row0_dev += advance afterwards
+ * (a second, one-thread launch on the same stream), so every replay of a captured graph draws fresh noise.
+ * Bit-identical to mfc_randn(seed, stream_id, *row0_dev, ...) followed by a cast to `dtype`. */
+int mfc_randn_dev(int dtype, uint64_t seed, uint64_t stream_id, int64_t* row0_dev, int64_t advance, int64_t B,
+                  int64_t D, void* out, void* stream);
 
 /* tanh-GELU on [M,N]: rows < act_rows primal, rows >= act_rows tangents
  * t*gelu'(pre[row-act_rows]); and its backward din = dout*gelu'(pre). */

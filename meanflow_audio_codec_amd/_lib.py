@@ -34,7 +34,7 @@ _lib = None
 # name -> (restype, argtypes); kept in sync with include/mfc.h by
 # tests/test_capi_symbols.py
 _P = c_void_p
-ABI_VERSION = 2          # MFC_ABI_VERSION of include/mfc.h
+ABI_VERSION = 3          # MFC_ABI_VERSION of include/mfc.h
 
 
 class AdamwItem(ctypes.Structure):
@@ -84,6 +84,7 @@ SIGNATURES = {
     "mfc_flow_prepare": (c_int, [c_int, c_int64, c_int64, _P, _P, _P, c_float, c_float, c_uint64, c_uint64,
                                  c_int64, c_int64, _P, _P, _P, _P]),
     "mfc_randn": (c_int, [c_uint64, c_uint64, c_int64, c_int64, c_int64, _P, _P]),
+    "mfc_randn_dev": (c_int, [c_int, c_uint64, c_uint64, _P, c_int64, c_int64, c_int64, _P, _P]),
     "mfc_gelu_fwd": (c_int, [c_int, c_int64, c_int64, c_int64, _P, _P, _P]),
     "mfc_gelu_bwd": (c_int, [c_int, c_int64, _P, _P, _P, _P]),
     "mfc_flow_loss": (c_int, [c_int, c_int, c_int, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, _P,

@@ -45,6 +45,15 @@ constexpr int NT = 256, NWAVES = 4, RPW = TH / NWAVES;
 constexpr int CS = 20;  // element stride of a 16-channel pixel row in LDS
 constexpr float LN_EPS = 1e-6f;
 constexpr float GRN_EPS = 1e-6f;
+// Profiling ablations are COMPILE-TIME only (-DMFC_CNX_ABL=bits builds a library that computes wrong results on purpose;
+// the shipped build defines nothing and no environment variable can switch any of this on): 1 no GELU arithmetic,
+// 2 one of the five conv steps, 4 no LayerNorm ladder, 8 skip the row chain, 16 request only the first tile's DMA,
+// 32 zero the gradient records.
+#if defined(MFC_CNX_ABL)
+constexpr bool ABL_NO_CHAIN = (MFC_CNX_ABL & 8) != 0, ABL_NO_DMA = (MFC_CNX_ABL & 16) != 0, ABL_NO_FLUSH = (MFC_CNX_ABL & 32) != 0;
+#else
+constexpr bool ABL_NO_CHAIN = false, ABL_NO_DMA = false, ABL_NO_FLUSH = false;
+#endif
 
 struct Dev {  // device pointers of mfc_cnx_params, by value
     const void* conv_w; const float* conv_b; const void* exp_w; const float* exp_b;
@@ -72,6 +81,18 @@ __device__ inline void land(const s16x4& v) { asm volatile("" ::"v"(v)); }
 // (Measured alternative: the same sum as one v_mfma_f32_16x16x4_f32 with A = ones, which contracts over lane >> 4 on
 // the mostly idle matrix pipe -- 3-7 % SLOWER on every kernel here: the dependent read of the MFMA result stalls the
 // wave longer than the eight VALU instructions of the swap ladder take to issue.)
+#if !defined(MFC_CNX_EXP)
+#define MFC_CNX_EXP 0
+#endif
+#if MFC_CNX_EXP & 1
+// experiment: the q-lane sums on the LDS crossbar (ds_bpermute: no VALU issue slots, ~100 cycles of latency other waves cover)
+__device__ inline float red_q(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ inline void red_q2(float& x, float& y) { x = red_q(x); y = red_q(y); }
+#else
 __device__ inline float red_q(float v) {
     // inline asm: with the builtin and identical operands hipcc (ROCm 7.2) folds the two results
     // into one register.  "s_nop 1" = the 2 wait states a VALU-written operand needs before
@@ -96,6 +117,7 @@ __device__ inline void red_q2(float& x, float& y) {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a: X X X X   b: Y Y Y Y
     x = a; y = b;
 }
+#endif
 __device__ inline float red_m(float v) {  // sum over the 16 lanes sharing (lane >> 4)
     v += __shfl_xor(v, 1);
     v += __shfl_xor(v, 2);
@@ -305,8 +327,8 @@ template <typename T> struct Halo {
         const int c = (4 * q) / EPC, w = (4 * q) % EPC;
         return ((hy * CPP + c) * HW + hx) * EPC + w;
     }
-    int hyx[NI];   // (hy << 8) | hx of this lane's chunk in instruction i, -1 past the end of the tile
-    int rel[NI];   // element offset of that chunk relative to the tile's origin pixel (y0, x0)
+    int hyx[NI];        // (hy << 8) | hx of this lane's chunk in instruction i, -1 past the end of the tile
+    uint32_t relb[NI];  // byte offset of that chunk relative to the tile's HALO origin pixel (y0 - 1, x0 - 1): never negative
     __device__ inline void init(int s, int wave, int lane) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -314,24 +336,39 @@ template <typename T> struct Halo {
             const int hy = ch / (CPP * HW), rem = ch - hy * (CPP * HW);
             const int part = rem / HW, hx = rem - part * HW;
             hyx[i] = ch < CHUNKS ? ((hy << 8) | hx) : -1;
-            rel[i] = ((hy - 1) * s + (hx - 1)) * 16 + part * EPC;
+            relb[i] = (uint32_t)(((hy * s + hx) * 16 + part * EPC) * (int)sizeof(T));
         }
     }
-    // request the halo of tile (y0, x0) of the [s, s, 16] image `img` into the LDS tile at byte address `dst`
+    // request the halo of tile (y0, x0) of the [s, s, 16] image `img` into the LDS tile at byte address `dst`.
+    // Interior tiles (the whole halo lies inside the image: ~90 % of them) take the scalar-base form of the DMA
+    // instruction -- address = SGPR pair + the lane's constant offset -- so a request costs no vector ALU work at all;
+    // tiles on the image border test every chunk and fetch the ones outside from 16 zero bytes.  Both forms issue
+    // the same number of VMEM instructions (vmcnt note).
     __device__ inline void request(uint32_t dst, const T* img, int s, int y0, int x0, int wave) const {
-        const int64_t org = ((int64_t)y0 * s + x0) * 16;
+        // halo origin; on a border tile it may lie before the image (only chunks inside the image are dereferenced)
+        const char* base = reinterpret_cast<const char*>(img + ((int64_t)(y0 - 1) * s + (x0 - 1)) * 16);
+#if MFC_CNX_EXP & 4
+        const bool interior = false;
+#else
+        const bool interior = y0 > 0 && x0 > 0 && y0 + TH < s && x0 + TW < s;
+#endif
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             if (hyx[i] >= 0) {
-                const int gy = y0 + (hyx[i] >> 8) - 1, gx = x0 + (hyx[i] & 255) - 1;
-                const bool in = (unsigned)gy < (unsigned)s && (unsigned)gx < (unsigned)s;
-                const T* gp = in ? img + org + rel[i] : reinterpret_cast<const T*>(&g_zero16);
                 // Inline asm, not __builtin_amdgcn_global_load_lds: the compiler cannot tell the two LDS buffers
                 // apart and would drain vmcnt before every LDS read of the tile being computed.  (Hiding a VMEM
                 // instruction from its in-order vmcnt model only makes the waits it inserts stricter.)
                 const uint32_t lds_addr = dst + (i * NWAVES + wave) * 1024;   // 64 lanes x 16 bytes per instruction
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                             :: "v"(gp), "s"(lds_addr) : "memory", "m0");
+                if (interior) {
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                                 :: "v"(relb[i]), "s"(base), "s"(lds_addr) : "memory", "m0");
+                } else {
+                    const int gy = y0 + (hyx[i] >> 8) - 1, gx = x0 + (hyx[i] & 255) - 1;
+                    const bool in = (unsigned)gy < (unsigned)s && (unsigned)gx < (unsigned)s;
+                    const void* gp = in ? static_cast<const void*>(base + relb[i]) : static_cast<const void*>(&g_zero16);
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                                 :: "v"(gp), "s"(lds_addr) : "memory", "m0");
+                }
             }
         }
     }
@@ -654,7 +691,6 @@ struct FwdArgs {
     const float* q; const float* qd;  // apply mode
     void* o; void* od;
     float* ws;   // stats mode: per-(workgroup, row) records of REC_STATS floats
-    int dbg;   // profiling ablations (env MFC_CNX_DBG): 1 = skip the row chain, 2 = request only the first tile
 };
 
 template <typename T, bool JVP>
@@ -669,11 +705,12 @@ __device__ inline void load_film(float* fsc, const float* sc, const float* sh, c
         }
     }
 }
+__device__ inline int rows_in_image(int s, int gy0) { const int n = s - gy0; return n < 0 ? 0 : (n > RPW ? RPW : n); }
 __device__ inline bool tile_on_border(int s, int y0, int x0) { return y0 == 0 || x0 == 0 || y0 + TH >= s || x0 + TW >= s; }
 
 // MODE 0: GRN statistics; MODE 1: apply GRN, contract, layer-scale, residual.
 template <typename T, bool JVP, int MODE>
-__global__ void __launch_bounds__(NT, (sizeof(T) == 2 && JVP && MODE == 0) ? 3 : 1)   // bf16 tangent statistics: <= 168 registers
+__global__ void __launch_bounds__(NT, sizeof(T) != 2 ? 1 : !JVP ? 4 : MODE == 0 ? 3 : 1)   // bf16: plain kernels <= 128 registers, tangent statistics <= 168
 cnx_fwd_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Frag<T>::type frag_t;
@@ -769,7 +806,7 @@ cnx_fwd_kernel(FwdArgs a) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < t1 && !(a.dbg & 2)) {
+        if (t + 1 < t1 && !ABL_NO_DMA) {
             hl.request(l.tile_addr(0, cur ^ 1), h0 + tnext.r * img, s, tnext.y0, tnext.x0, wave);
             if constexpr (JVP) hl.request(l.tile_addr(1, cur ^ 1), h0d + tnext.r * img, s, tnext.y0, tnext.x0, wave);
         }
@@ -778,8 +815,34 @@ cnx_fwd_kernel(FwdArgs a) {
         const T* tiled = l.tile(JVP ? 1 : 0, cur);
         const bool border = tile_on_border(s, y0, x0);
         const int gx = x0 + m;
+        // Tile rows below the image (only in the last row of tiles: s % 16 of its 16 rows exist) are skipped -- nothing
+        // of them is stored or summed.  nrows is wave-uniform.
+        const int nrows = ABL_NO_CHAIN ? 0 : rows_in_image(s, y0 + wave * RPW);
+#if MFC_CNX_EXP & 2
+        if constexpr (MODE == 0 && !JVP) {
+            // experiment: two independent tile rows per iteration (the compiler interleaves the two chains)
 #pragma unroll 1
-        for (int ri = 0; ri < ((a.dbg & 1) ? 0 : RPW); ++ri) {
+            for (int ri = 0; ri < RPW; ri += 2) {
+                const int y = wave * RPW + ri;
+                const int gy = y0 + y;
+                if (gy >= s) continue;
+                const bool ok0 = gx < s, ok1 = gy + 1 < s && gx < s;
+                RowFwd<T, JVP> f0, f1;
+                chain_row<T, JVP, false, K32>(tile, tiled, l.wc0, w, rw, border, gy, gx, s, y, q, m, lane, f0);
+                chain_row<T, JVP, false, K32>(tile, tiled, l.wc0, w, rw, border, gy + 1, gx, s, y + 1, q, m, lane, f1);
+                if (ok0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) s1[j] = fma4(f0.g[j], f0.g[j], s1[j]);
+                }
+                if (ok1) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) s1[j] = fma4(f1.g[j], f1.g[j], s1[j]);
+                }
+            }
+        } else
+#endif
+#pragma unroll 1
+        for (int ri = 0; ri < nrows; ++ri) {
             const int y = wave * RPW + ri;
             const int gy = y0 + y;
             const bool ok = gy < s && gx < s;
@@ -830,6 +893,15 @@ cnx_fwd_kernel(FwdArgs a) {
                 }
             }
         }
+        if constexpr (MODE == 1) {
+            // the skipped rows' stores are still issued, steered out of bounds: the wait below counts them (vmcnt note)
+            const float zv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int ri = nrows; ri < RPW; ++ri) {
+                buf_st4(rs_o, BUF_OOB, zv, (const T*)nullptr);
+                if constexpr (JVP) buf_st4(rs_od, BUF_OOB, zv, (const T*)nullptr);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         // this wave's share of tile t+1 has landed once at most the S_VMEM stores issued after the request are pending
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_VMEM) : "memory");
@@ -848,7 +920,6 @@ struct BwdArgs {
     const void* dout; const void* dc1_in;
     float* dq; void* dc1; void* dh0; float* dsc; float* dsh;
     float* ws;   // partial-sum records (see REC_*)
-    int dbg;
 };
 
 // read a [16 pixel][CS] scratch tile as an operand that has the PIXEL as k:
@@ -995,8 +1066,9 @@ cnx_bwd_kernel(BwdArgs a) {
         const T* tile = l.tile(0, cur);
         const T* dotile = l.tile(MODE == 1 ? 1 : 0, cur);
         const bool border = tile_on_border(s, y0, x0);
+        const int nrows = rows_in_image(s, y0 + wave * RPW);   // rows below the image: dout = 0, no contribution -- skipped
 #pragma unroll 1
-        for (int ri = 0; ri < RPW; ++ri) {
+        for (int ri = 0; ri < nrows; ++ri) {
             const int y = wave * RPW + ri;
             const int gy = y0 + y;
             const bool ok = gy < s && gx < s;
@@ -1079,6 +1151,11 @@ cnx_bwd_kernel(BwdArgs a) {
                 lds_fence();
             }
         }
+        if constexpr (MODE == 1) {       // the skipped rows' dc1 stores, out of bounds: the wait below counts them (vmcnt note)
+            const float zv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int ri = nrows; ri < RPW; ++ri) buf_st4(rs_dc, BUF_OOB, zv, (const T*)nullptr);
+        }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_VMEM) : "memory");   // this wave's share of tile t+1 has landed
     }
@@ -1118,7 +1195,7 @@ cnx_bwd_kernel(BwdArgs a) {
             __syncthreads();
         }
         float* rec = a.ws + (int64_t)blockIdx.x * REC_MAIN;
-        for (int i = threadIdx.x; i < REC_MAIN; i += NT) rec[i] = (a.dbg & 1) ? 0.f : scratch[i];
+        for (int i = threadIdx.x; i < REC_MAIN; i += NT) rec[i] = ABL_NO_FLUSH ? 0.f : scratch[i];
     }
 }
 
@@ -1147,7 +1224,7 @@ __device__ inline typename Frag<T>::type pix_k_tile(const T* tile, int hy, int h
 // A is the 9 pixel-contracting MFMAs on the raw tile; B is ONE more MFMA whose A operand is the 0/1 tap-validity
 // mask (row = tap, k = pixel; all ones on interior tiles).  Both are flushed when the workgroup's row r changes.
 template <typename T>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, sizeof(T) == 2 ? 3 : 1)   // bf16: <= 168 registers, three workgroups per CU (LDS allows three)
 cnx_bwd_conv_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Frag<T>::type frag_t;
@@ -1222,7 +1299,7 @@ cnx_bwd_conv_kernel(BwdArgs a) {
         for (int t = 0; t < 9; ++t) aWc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         aB = f32x4{0.f, 0.f, 0.f, 0.f};
         float* rec = a.ws + ((int64_t)blockIdx.x * a.geo.kmax + krow) * REC_CONV;
-        for (int i = threadIdx.x; i < NW + 32; i += NT) rec[i] = (a.dbg & 1) ? 0.f : scratch[i];
+        for (int i = threadIdx.x; i < NW + 32; i += NT) rec[i] = ABL_NO_FLUSH ? 0.f : scratch[i];
         ++krow;
         __syncthreads();
     };
@@ -1295,8 +1372,9 @@ cnx_bwd_conv_kernel(BwdArgs a) {
         const T* dtile = l.tile(1, cur);
         const float* rtile = l.rho + cur * (TH * TW);
         const bool border = tile_on_border(s, y0, x0);
+        const int nrows = rows_in_image(s, y0 + wave * RPW);   // rows below the image: dout = dc1 = 0, no contribution -- skipped
 #pragma unroll 1
-        for (int ri = 0; ri < RPW; ++ri) {
+        for (int ri = 0; ri < nrows; ++ri) {
             const int y = wave * RPW + ri;
             const int gy = y0 + y;
             const bool ok = gy < s && gx < s;
@@ -1353,6 +1431,11 @@ cnx_bwd_conv_kernel(BwdArgs a) {
                 buf_st4(rs_dh, ok ? (uint32_t)((((int64_t)gy * s + gx) * 16 + 4 * q) * sizeof(T)) : BUF_OOB, dx, (const T*)nullptr);
             }
         }
+        {                                // the skipped rows' stores, out of bounds: the wait below counts them (vmcnt note)
+            const float zv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int ri = nrows; ri < RPW; ++ri) buf_st4(rs_dh, BUF_OOB, zv, (const T*)nullptr);
+        }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_VMEM) : "memory");   // this wave's share of tile t+1 has landed
     }
@@ -1396,7 +1479,7 @@ cnx_bwd_conv_kernel(BwdArgs a) {
     }
     if (threadIdx.x < REC_TAIL)
         a.ws[(int64_t)gridDim.x * a.geo.kmax * REC_CONV + (int64_t)blockIdx.x * REC_TAIL + threadIdx.x] =
-            (a.dbg & 1) ? 0.f : scratch[threadIdx.x];
+            ABL_NO_FLUSH ? 0.f : scratch[threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------
@@ -1574,9 +1657,9 @@ constexpr int MAX_S = 8000;   // one [s, s, 16] fp32 image must stay below the 4
 
 template <typename K, typename A>
 inline int launch_k(K kern, int64_t grid, size_t lds, hipStream_t st, const A& args) {
-    // MFC_CNX_LDS_PAD (bytes): occupancy probe -- unused extra LDS per workgroup, so fewer workgroups fit a CU
-    static const size_t pad = getenv("MFC_CNX_LDS_PAD") ? (size_t)atoll(getenv("MFC_CNX_LDS_PAD")) : 0;
-    lds += pad;
+#if defined(MFC_CNX_LDS_PAD)
+    lds += MFC_CNX_LDS_PAD;   // occupancy probe (compile-time): unused extra LDS per workgroup, so fewer workgroups fit a CU
+#endif
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, args);
     return mfc_launch_status();
@@ -1622,8 +1705,6 @@ int fwd_common(int dtype, int mode, int64_t R, int s, const void* h0, const void
     a.geo = make_geo(R, s, max_blocks(mode == 0 ? (jvp ? K_STATS_JVP : K_STATS) : (jvp ? K_APPLY_JVP : K_APPLY)), grid);
     a.h0 = h0; a.h0d = h0dot; a.sc = scale; a.sh = shift; a.scd = scaledot; a.shd = shiftdot;
     a.p = to_dev(p); a.S1 = S1; a.S2 = S2; a.q = q; a.qd = qdot; a.o = o; a.od = odot; a.ws = ws;
-    static const int dbg = getenv("MFC_CNX_DBG") ? atoi(getenv("MFC_CNX_DBG")) : 0;
-    a.dbg = dbg;
     hipStream_t st = (hipStream_t)stream;
     int rc = dtype == MFC_F32 ? fwd_launch<float>(jvp, mode, a, grid, st) : fwd_launch<u16>(jvp, mode, a, grid, st);
     if (!rc && mode == 0) rc = reduce_rows(ws, a.geo, REC_STATS, 0, jvp ? 64 : 32, 32, S1, S2, st);
@@ -1679,8 +1760,6 @@ extern "C" int mfc_grn_bwd_finalize(int64_t R, const float* G, const float* dq, 
     return mfc_launch_status();
 }
 
-static const int BWD_DBG = getenv("MFC_CNX_BWD_DBG") ? atoi(getenv("MFC_CNX_BWD_DBG")) : 0;
-
 extern "C" int mfc_cnx_bwd_stats(int dtype, int64_t R, int s, const void* h0, const float* scale,
                                  const float* shift, const mfc_cnx_params* p, const float* q, const void* dout,
                                  float* dq, float* ws, void* stream) {
@@ -1691,7 +1770,7 @@ extern "C" int mfc_cnx_bwd_stats(int dtype, int64_t R, int s, const void* h0, co
     int64_t grid;
     a.geo = make_geo(R, s, max_blocks(K_BWD_STATS), grid);
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(nullptr);
-    a.q = q; a.dout = dout; a.dq = dq; a.ws = ws; a.dbg = BWD_DBG;
+    a.q = q; a.dout = dout; a.dq = dq; a.ws = ws;
     hipStream_t st = (hipStream_t)stream;
     int rc = dtype == MFC_F32 ? launch_k(cnx_bwd_kernel<float, 0>, grid, lds2_bytes<float>(1, false), st, a)
                               : launch_k(cnx_bwd_kernel<u16, 0>, grid, lds2_bytes<u16>(1, false), st, a);
@@ -1710,7 +1789,7 @@ extern "C" int mfc_cnx_bwd_main(int dtype, int64_t R, int s, const void* h0, con
     int64_t grid;
     a.geo = make_geo(R, s, max_blocks(K_BWD_MAIN), grid);
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(g);
-    a.q = q; a.kG = kG; a.dout = dout; a.dc1 = dc1; a.ws = ws; a.dbg = BWD_DBG;
+    a.q = q; a.kG = kG; a.dout = dout; a.dc1 = dc1; a.ws = ws;
     hipStream_t st = (hipStream_t)stream;
     int rc = dtype == MFC_F32 ? launch_k(cnx_bwd_kernel<float, 1>, grid, lds2_bytes<float>(2, true), st, a)
                               : launch_k(cnx_bwd_kernel<u16, 1>, grid, lds2_bytes<u16>(2, true), st, a);
@@ -1734,7 +1813,7 @@ extern "C" int mfc_cnx_bwd_conv(int dtype, int64_t R, int s, const void* h0, con
     int64_t grid;
     a.geo = make_geo(R, s, max_blocks(K_BWD_CONV), grid);
     a.h0 = h0; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.g = to_devg(g);
-    a.rho = rho0; a.dc1_in = dc1; a.dout = dout; a.dh0 = dh0; a.dsc = dscale; a.dsh = dshift; a.ws = ws; a.dbg = BWD_DBG;
+    a.rho = rho0; a.dc1_in = dc1; a.dout = dout; a.dh0 = dh0; a.dsc = dscale; a.dsh = dshift; a.ws = ws;
     hipStream_t st = (hipStream_t)stream;
     int rc = dtype == MFC_F32 ? launch_k(cnx_bwd_conv_kernel<float>, grid, lds_bwd_conv_bytes<float>(), st, a)
                               : launch_k(cnx_bwd_conv_kernel<u16>, grid, lds_bwd_conv_bytes<u16>(), st, a);

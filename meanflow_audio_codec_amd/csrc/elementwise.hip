@@ -143,6 +143,25 @@ __global__ void randn_kernel(uint64_t seed, uint64_t stream, int64_t row0, int64
     }
 }
 
+// The same draw with the first global row taken from DEVICE memory and the result written in the storage dtype: the
+// launch is then a fixed graph node whose noise still changes from replay to replay (randn_advance_kernel moves the
+// counter after every block has read it: stream order).
+template <typename T>
+__global__ void randn_dev_kernel(uint64_t seed, uint64_t stream, const int64_t* row0_dev, int64_t B, int64_t D, T* out) {
+    const int64_t row0 = *row0_dev;
+    const int64_t quads = (D + 3) / 4;
+    const int64_t total = B * quads;
+    for (int64_t o = blockIdx.x * (int64_t)ET + threadIdx.x; o < total; o += (int64_t)gridDim.x * ET) {
+        const int64_t b = o / quads, qd = o - b * quads;
+        float e4[4];
+        normal4(seed, (uint32_t)stream, (uint64_t)(row0 + b), (uint32_t)qd, e4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * qd + i < D) St<T>::st(out + b * D + 4 * qd + i, e4[i]);
+    }
+}
+__global__ void randn_advance_kernel(int64_t* row0_dev, int64_t advance) { *row0_dev += advance; }
+
 // ---- GELU on [M,N] with tangent rows / backward ------------------------------
 template <typename T>
 __global__ void gelu_fwd_kernel(int64_t M, int64_t N, int64_t act_rows, const T* pre, T* out) {
@@ -419,6 +438,21 @@ extern "C" int mfc_randn(uint64_t seed, uint64_t stream_id, int64_t row0, int64_
     if (B <= 0 || D <= 0) return MFC_EINVAL;
     hipLaunchKernelGGL(randn_kernel, dim3(grid_for(B * ((D + 3) / 4))), dim3(ET), 0, (hipStream_t)stream, seed,
                        stream_id, row0, B, D, out);
+    return mfc_launch_status();
+}
+
+extern "C" int mfc_randn_dev(int dtype, uint64_t seed, uint64_t stream_id, int64_t* row0_dev, int64_t advance, int64_t B,
+                             int64_t D, void* out, void* stream) {
+    if (!out || !row0_dev) return MFC_EFAULT;
+    if (B <= 0 || D <= 0 || !DT_OK(dtype)) return MFC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_F32)
+        hipLaunchKernelGGL(randn_dev_kernel<float>, dim3(grid_for(B * ((D + 3) / 4))), dim3(ET), 0, st, seed, stream_id,
+                           (const int64_t*)row0_dev, B, D, (float*)out);
+    else
+        hipLaunchKernelGGL(randn_dev_kernel<u16>, dim3(grid_for(B * ((D + 3) / 4))), dim3(ET), 0, st, seed, stream_id,
+                           (const int64_t*)row0_dev, B, D, (u16*)out);
+    if (advance) hipLaunchKernelGGL(randn_advance_kernel, dim3(1), dim3(1), 0, st, row0_dev, advance);
     return mfc_launch_status();
 }
 

@@ -78,22 +78,28 @@ def one_step_decode(model, w, eps: torch.Tensor, latents: torch.Tensor | None) -
 
 
 class GraphedDecoder:
-    """hipGraph of: noise -> n-step Heun (or the 1-NFE decode) -> un-flatten -> IMDCT.
+    """hipGraph of: Philox noise -> n-step Heun (or the 1-NFE decode) -> un-flatten -> IMDCT.
 
-    ``n_steps == 0`` selects the 1-NFE decode.  Static shapes: batch B, latents fixed at capture."""
+    ``n_steps == 0`` selects the 1-NFE decode.  Static shapes: batch B, latents fixed at capture.  The noise draw is
+    a node of the graph (``mfc_randn_dev``: the global row counter lives in a device scalar that the graph advances by
+    B after every draw), so ONE replay is the whole "noise -> audio" path and consecutive replays decode fresh noise;
+    ``fresh_noise=False`` rewinds the counter first and so repeats the previous draw."""
+
+    noise_in_graph = True
 
     def __init__(self, model, w, B: int, latents: torch.Tensor | None, *, n_steps: int = 0,
                  token_shape: tuple[int, int] | None = None, mdct_config=None, seed: int = 0, device="cuda"):
         from ..preprocessing.mdct import imdct
         self.model, self.w, self.B, self.n_steps = model, w, B, n_steps
         self.latents = latents
-        self.eps = torch.empty((B, model.noise_dimension), dtype=torch.float32, device=device)
+        self.eps = torch.empty((B, model.noise_dimension), dtype=model.dtype, device=device)   # the start noise of the last replay
+        self.row0 = torch.zeros(1, dtype=torch.int64, device=device)     # first global row of the NEXT draw
         self.seed = seed
         self.calls = 0
         self._imdct = imdct
 
         def body():
-            e = self.eps if model.dtype == torch.float32 else ops.cast(self.eps, model.dtype)
+            e = ops.randn_dev(self.seed, 0x6400, self.row0, B, self.eps)
             if n_steps == 0:
                 x0 = one_step_decode(model, w, e, latents)
             else:
@@ -105,9 +111,9 @@ class GraphedDecoder:
 
         self._body = body
         getattr(w, "wait_all", lambda: None)()   # no in-flight weight gathers may be awaited inside the capture
-        self._draw()
         body()                                   # warm-up: allocations, function attributes
         torch.cuda.synchronize()
+        self.row0.zero_()                        # the warm-up's draw does not count
         self.graph = torch.cuda.CUDAGraph()
         # The cyclic garbage collector must not run inside the capture: collecting an unrelated object that owns device
         # resources (an older hipGraph, an event) issues HIP calls that are illegal while a stream is capturing and
@@ -123,14 +129,14 @@ class GraphedDecoder:
             if was_enabled:
                 gc.enable()
 
-    def _draw(self):
-        ops_out = ops.randn(self.seed, 0x6400, self.calls * self.B, self.B, self.model.noise_dimension,
-                            device=self.eps.device)
-        self.eps.copy_(ops_out)
-        self.calls += 1
+    def noise_of_call(self, k: int) -> torch.Tensor:
+        """The fp32 start noise replay number ``k`` (0-based) decodes: rows [k B, (k+1) B) of Philox stream 0x6400."""
+        return ops.randn(self.seed, 0x6400, k * self.B, self.B, self.model.noise_dimension, device=self.eps.device)
 
     def __call__(self, fresh_noise: bool = True) -> torch.Tensor:
-        if fresh_noise:
-            self._draw()
+        if not fresh_noise and self.calls > 0:
+            self.row0.sub_(self.B)               # repeat the previous draw
+            self.calls -= 1
         self.graph.replay()
+        self.calls += 1
         return self.out

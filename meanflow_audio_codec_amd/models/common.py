@@ -42,6 +42,26 @@ def init_from_shapes(shapes: dict, seed: int, device, big_threshold: int = 1 << 
     return out
 
 
+def init_into(params: dict, shapes: dict, seed: int) -> dict:
+    """``init_from_shapes`` into EXISTING tensors (same generator sequence, so the values equal a fresh
+    ``init_from_shapes(shapes, seed, device)`` bit for bit): re-initialisation without a second parameter tree."""
+    dev = next(iter(params.values())).device
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    for name, shape in shapes.items():
+        t = params[name]
+        assert tuple(t.shape) == tuple(shape), name
+        leaf = name.rsplit("/", 1)[-1]
+        if leaf == "kernel":
+            lecun_normal_(t, math.prod(shape[:-1]), gen)
+        elif leaf == "layer_scale_gamma":
+            t.fill_(1e-6)
+        elif leaf in ("query_tokens", "condition_tokens"):
+            t.normal_(0, 0.02, generator=gen)
+        else:
+            t.zero_()
+    return params
+
+
 def auto_splitk(M: int, N: int, K: int) -> int:
     """K slices of a product with few output tiles (a pure function of the shape: the slab sums are fixed-order, so
     results are reproducible).  One or two output tiles (the K = D / K = S products of a ConvFlow block): 512 slices =

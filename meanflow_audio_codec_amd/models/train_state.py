@@ -101,16 +101,31 @@ class TrainState:
 
     def grad_buffers(self) -> dict:
         """Persistent gradient buffers: big kernels in the compute dtype (written once per step by the
-        weight-gradient GEMM), everything else fp32."""
+        weight-gradient GEMM), everything else fp32.  Buffers are created on first access (``LazyGrads``): in the
+        fused single-GPU schedule the big kernels' gradients are consumed inside the weight-gradient GEMM and never
+        exist, so their 2 bytes per parameter (27 GB at the literal shape) are never allocated."""
         if self._grads is None:
-            g = {}
-            for k, p in self.params.items():
-                dt = self._work_dtype(k)
-                if "/conv_block/" in k:
-                    dt = torch.float32   # fp32 accumulators (+=) of the spatial kernels' fixed-order reductions
-                g[k] = torch.zeros(p.shape, dtype=dt, device=p.device)
-            self._grads = g
+            self._grads = LazyGrads(self)
         return self._grads
+
+    def reinit(self, seed: int = 0, tx: AdamW | None = None):
+        """Back to a freshly initialised state IN PLACE (no second copy of a 13.7 B-parameter tree): every leaf is
+        re-drawn by the model's own initialiser one leaf at a time, the moments are zeroed, the step counter reset and
+        the working copies refreshed."""
+        fresh_gen = getattr(self.model, "init_into", None)
+        if fresh_gen is not None:
+            fresh_gen(self.params, seed)
+        else:
+            from .common import init_into
+            init_into(self.params, self.model.param_shapes(), seed)
+        for d in (self.opt_state["mu"], self.opt_state["nu"]):
+            for v in d.values():
+                v.zero_()
+        self.step = 0
+        if tx is not None:
+            self.tx = tx
+        self.refresh_work()
+        return self
 
     def fused_updater(self, names=None):
         """For a step opened with ``begin_update``: an object whose ``dw(name, A, dY, alpha)`` computes the weight
@@ -137,14 +152,20 @@ class TrainState:
         names = list(names)
         small = [k for k in names if self.params[k].is_cuda and self.params[k].numel() < self.MULTI_TENSOR_BELOW]
         if len(small) > 1:
-            mu = self.opt_state["mu"]
-            key = (tuple(small), tuple((grads[k].data_ptr(), self.params[k].data_ptr(), mu[k].data_ptr()) for k in small))
+            mu, nu = self.opt_state["mu"], self.opt_state["nu"]
+            # every pointer the descriptor table holds is part of the key (a reallocated working copy or moment must
+            # never be updated through a stale table); dict.__getitem__: the key must not consume a pending-gather event
+            key = (tuple(small), tuple((grads[k].data_ptr(), self.params[k].data_ptr(), mu[k].data_ptr(), nu[k].data_ptr(),
+                                        dict.__getitem__(self.work, k).data_ptr()) for k in small))
             cache = self.__dict__.setdefault("_multi_cache", {})
             ent = cache.get(key)
+            if ent is not None and self.work.pending:
+                for k in small:          # a cached table still has to wait for in-flight all-gathers of these leaves
+                    self.work._arrive(k)
             if ent is None:
                 leaves = [(self.params[k], grads[k], self.opt_state["mu"][k], self.opt_state["nu"][k],
                            self.work[k] if self.work[k].dtype == torch.bfloat16 else None) for k in small]
-                if len(cache) > 16:
+                if len(cache) > max(16, getattr(self.model, "num_blocks", 0) + 2):
                     cache.clear()
                 ent = cache[key] = (ops.adamw_multi_items(leaves), leaves)      # the tensors stay alive with the table
             (items, n), _ = ent
@@ -160,6 +181,50 @@ class TrainState:
         self.step += 1
         self.apply_subset(list(self.params), grads, grad_scale)
         return self
+
+
+class LazyGrads(dict):
+    """name -> gradient buffer, allocated (zero-filled) on first access.  Iteration, ``in`` and ``len`` cover every
+    parameter name whether or not its buffer exists yet."""
+
+    def __init__(self, state: TrainState):
+        super().__init__()
+        self._state = state
+
+    def __missing__(self, k):
+        st = self._state
+        p = st.params[k]                       # KeyError for an unknown name, like a plain dict
+        dt = st._work_dtype(k)
+        if "/conv_block/" in k:
+            dt = torch.float32                 # fp32 accumulators (+=) of the spatial kernels' fixed-order reductions
+        t = torch.zeros(p.shape, dtype=dt, device=p.device)
+        dict.__setitem__(self, k, t)
+        return t
+
+    def get(self, k, default=None):
+        return self[k] if k in self._state.params else default
+
+    def __contains__(self, k):
+        return k in self._state.params
+
+    def __iter__(self):
+        return iter(self._state.params)
+
+    def __len__(self):
+        return len(self._state.params)
+
+    def keys(self):
+        return self._state.params.keys()
+
+    def items(self):
+        return ((k, self[k]) for k in self._state.params)
+
+    def values(self):
+        return (self[k] for k in self._state.params)
+
+    def allocated(self):
+        """the buffers that exist (dict view, no allocation)"""
+        return dict(dict.items(self))
 
 
 class FusedUpdater:

@@ -308,6 +308,16 @@ def randn(seed, stream_id, row0, B, D, device="cuda"):
     return out
 
 
+def randn_dev(seed, stream_id, row0_dev, advance, out):
+    """``mfc_randn_dev``: N(0,1) into ``out`` [B, D] (fp32 or bf16) keyed by the global row counter ``row0_dev`` (an
+    int64 device scalar), which is advanced by ``advance`` afterwards -- a graph-capturable noise draw."""
+    B, D = out.shape
+    assert row0_dev.dtype == torch.int64 and row0_dev.numel() == 1 and row0_dev.is_cuda and out.is_contiguous()
+    _lib.check(_lib.lib().mfc_randn_dev(_lib.dtype_code(out.dtype), seed, stream_id, row0_dev.data_ptr(), int(advance), B, D,
+                                        out.data_ptr(), _lib.stream_ptr()), "mfc_randn_dev")
+    return out
+
+
 def data_size_of(Bglobal: int, data_proportion: float) -> int:
     """``data_size = int(batch_size * data_proportion)`` of utils.sample_tr (utils.py:41), in Python double arithmetic
     like the reference -- the ONE place this integer is computed (kernel and host bookkeeping both take it from here)."""

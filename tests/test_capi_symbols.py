@@ -40,7 +40,7 @@ def test_header_and_ctypes_signatures_agree():
 
 def test_no_gpu_entry_points():
     l = _lib.lib()
-    assert l.mfc_abi_version() == 2          # MFC_ABI_VERSION of include/mfc.h
+    assert l.mfc_abi_version() == 3          # MFC_ABI_VERSION of include/mfc.h
     assert b"gfx950" in l.mfc_build_info()
     # reference frame-count rule, preprocessing/mdct.py:491
     assert l.mfc_mdct_num_frames(196608, 512, 256) == 767

@@ -22,18 +22,28 @@ w = {"conv_w": (torch.randn(3, 3, 16, 16, device=dev, generator=g) / 12).to(dtyp
 grads = {k: torch.zeros(v.shape, dtype=torch.float32, device=dev) for k, v in w.items()}
 h0, rho = ops.ln16(h0)
 o, _, G, q = ops.cnx_forward(h0, sc, sh, w, s)
-for rep in range(3):
+NREP = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+best = {}
+order = []
+for rep in range(NREP):
     _lib.enable_timing()
     ops.cnx_forward(h0, sc, sh, w, s)
     ops.cnx_forward(h0, sc, sh, w, s, h0dot=h0d, scaledot=sc, shiftdot=sh)
     ops.cnx_backward(h0, sc, sh, w, s, G, q, dout, grads, rho0=rho)
     torch.cuda.synchronize()
-    rec = _lib.disable_timing()
-px = R * s * s
-if True:
-    for name, ints, nn, a, b in rec:
+    for name, ints, nn, a, b in _lib.disable_timing():
         if not name.startswith("mfc_cnx"):
             continue
-        ms = a.elapsed_time(b)
         jvp = nn[1] if name in ("mfc_cnx_stats", "mfc_cnx_apply") else False
-        print(f"{name:22s} jvp={int(jvp)} {ms:8.3f} ms  {ms * 1e6 / px:7.2f} ns/pixel")
+        k = (name, int(jvp))
+        if k not in best:
+            order.append(k)
+            best[k] = []
+        best[k].append(a.elapsed_time(b))
+px = R * s * s
+tot = 0.0
+for k in order:
+    v = sorted(best[k])
+    tot += v[0]
+    print(f"{k[0]:22s} jvp={k[1]} min {v[0]:7.3f} ms  median {v[len(v) // 2]:7.3f} ms  {v[0] * 1e6 / px:6.2f} ns/pixel")
+print(f"sum of minima {tot:7.3f} ms")
