@@ -40,7 +40,8 @@ extern "C" {
 /* library / ABI version and a one-line description of the build.  Version 2 (round 2): row_stride / data_size arguments
  * of mfc_sample_tr and mfc_flow_prepare, caller-owned workspaces instead of atomics (mfc_gemm_ws_elems,
  * mfc_cnx_ws_elems, MFC_FLOW_LOSS_WS_PER_ROW), colsum output of mfc_gemm_adamw.  Version 3 (round 3): additions only --
- * mfc_randn_dev (noise draw as a graph node). */
+ * mfc_randn_dev (noise draw as a graph node); mfc_cnx_stats_save / mfc_cnx_apply_n1 / mfc_cnx_bwd_stats_n1 /
+ * mfc_cnx_bwd_main_n1 (ConvNeXt passes from a kept n1). */
 #define MFC_ABI_VERSION 3
 int mfc_abi_version(void);
 const char* mfc_build_info(void);
@@ -212,6 +213,27 @@ int mfc_grn_bwd_finalize(int64_t R, const float* G, const float* dq, float* kG, 
 int mfc_cnx_bwd_main(int dtype, int64_t R, int s, const void* h0, const float* scale, const float* shift,
                      const mfc_cnx_params* p, const float* q, const float* kG, const void* dout,
                      void* dc1, const mfc_cnx_grads* g, float* ws, void* stream);
+
+/* ---- the same passes starting from a kept n1 (ABI 3) ----------------------------------------------------------
+ * Everything downstream of n1 = LN_C(conv3x3(FiLM(h1))) (conv_flow.py:74-84) is per pixel, so a statistics pass that
+ * keeps n1 and its 1/sigma lets the apply pass and the first two reverse passes run as plain streaming kernels (no
+ * halo, no repeated conv / LayerNorm).  Results equal the h1-based entry points up to the rounding of n1 to `dtype`
+ * (bit-identical forward in fp32 storage; in bf16 the expansion consumed the same bf16 n1 anyway). */
+
+/* mfc_cnx_stats that also writes n1 [R,s,s,16] (dtype) and rho1 [R,s,s] (fp32) for the primal rows. */
+int mfc_cnx_stats_save(int dtype, int64_t R, int s, const void* h1, const void* h1dot,
+                       const float* scale, const float* shift, const float* scaledot, const float* shiftdot,
+                       const mfc_cnx_params* p, float* S1, float* S2, float* ws, void* n1_out, float* rho1_out,
+                       void* stream);
+/* mfc_cnx_apply (primal rows only) from n1; h1 is read for the residual branch o = ... + FiLM(h1). */
+int mfc_cnx_apply_n1(int dtype, int64_t R, int s, const void* n1, const void* h1, const float* scale,
+                     const float* shift, const mfc_cnx_params* p, const float* q, void* o, void* stream);
+/* mfc_cnx_bwd_stats / mfc_cnx_bwd_main from n1 (and rho1): same outputs, same workspace contract. */
+int mfc_cnx_bwd_stats_n1(int dtype, int64_t R, int s, const void* n1, const mfc_cnx_params* p, const float* q,
+                         const void* dout, float* dq, float* ws, void* stream);
+int mfc_cnx_bwd_main_n1(int dtype, int64_t R, int s, const void* n1, const float* rho1, const mfc_cnx_params* p,
+                        const float* q, const float* kG, const void* dout, void* dc1, const mfc_cnx_grads* g,
+                        float* ws, void* stream);
 
 /* backward pass 3: dh0 = LN/FiLM-backward(conv3x3^T(dc1) + dout); gradients of conv_w, conv_b, con_b and
  * grn_beta (the last two are linear in sum_hw dout); dscale/dshift [R,16] fp32 (overwritten). */

@@ -84,15 +84,6 @@ __device__ inline void land(const s16x4& v) { asm volatile("" ::"v"(v)); }
 #if !defined(MFC_CNX_EXP)
 #define MFC_CNX_EXP 0
 #endif
-#if MFC_CNX_EXP & 1
-// experiment: the q-lane sums on the LDS crossbar (ds_bpermute: no VALU issue slots, ~100 cycles of latency other waves cover)
-__device__ inline float red_q(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
-}
-__device__ inline void red_q2(float& x, float& y) { x = red_q(x); y = red_q(y); }
-#else
 __device__ inline float red_q(float v) {
     // inline asm: with the builtin and identical operands hipcc (ROCm 7.2) folds the two results
     // into one register.  "s_nop 1" = the 2 wait states a VALU-written operand needs before
@@ -117,7 +108,6 @@ __device__ inline void red_q2(float& x, float& y) {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a: X X X X   b: Y Y Y Y
     x = a; y = b;
 }
-#endif
 __device__ inline float red_m(float v) {  // sum over the 16 lanes sharing (lane >> 4)
     v += __shfl_xor(v, 1);
     v += __shfl_xor(v, 2);
@@ -247,9 +237,10 @@ inline Geo make_geo(int64_t R, int s, int64_t maxBlocks, int64_t& grid) {
 // REC_DQ backward statistic [dq 32], REC_CONV [conv_w 2304 | dscale 16 | dshift 16].  Per workgroup: REC_MAIN
 // [con_w 512 | exp_w 512 | ls 16 | exp_b 32], REC_TAIL [con_b 16 | conv_b 16 | grn_beta 32].
 constexpr int REC_STATS = 64, REC_DQ = 32, REC_CONV = 9 * 256 + 32, REC_MAIN = 1024 + 48, REC_TAIL = 64;
-inline int64_t ws_elems_for(int64_t R, int s, int64_t maxBlocks) {
+inline Geo make_pix_geo(int64_t R, int s, int64_t maxBlocks, int64_t& grid);
+inline int64_t ws_elems_for(int64_t R, int s, int64_t maxBlocks, bool pix = false) {
     int64_t grid;
-    const Geo g = make_geo(R, s, maxBlocks, grid);
+    const Geo g = pix ? make_pix_geo(R, s, maxBlocks, grid) : make_geo(R, s, maxBlocks, grid);
     const int64_t a = grid * g.kmax * REC_CONV + grid * REC_TAIL, b = grid * REC_MAIN, c = grid * g.kmax * REC_STATS;
     return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
@@ -312,6 +303,13 @@ __device__ inline f32x4 buf_ld_frag(__amdgpu_buffer_rsrc_t rs, uint32_t off, con
 }
 __device__ inline s16x4 buf_ld_frag(__amdgpu_buffer_rsrc_t rs, uint32_t off, const u16*) {
     return __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+}
+
+__device__ inline void buf_st_frag(__amdgpu_buffer_rsrc_t rs, uint32_t off, const f32x4& f) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), rs, off, 0, 0);
+}
+__device__ inline void buf_st_frag(__amdgpu_buffer_rsrc_t rs, uint32_t off, const s16x4& f) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f), rs, off, 0, 0);
 }
 
 template <typename T> struct Halo {
@@ -691,6 +689,7 @@ struct FwdArgs {
     const float* q; const float* qd;  // apply mode
     void* o; void* od;
     float* ws;   // stats mode: per-(workgroup, row) records of REC_STATS floats
+    void* n1_out; float* rho1_out;   // stats mode, optional: n1 = LN(c1) [R, s, s, 16] (storage dtype) and its 1/sigma [R, s, s]
 };
 
 template <typename T, bool JVP>
@@ -729,7 +728,9 @@ cnx_fwd_kernel(FwdArgs a) {
     hl.init(s, wave, lane);
     constexpr bool K32 = JVP || MODE == 0;   // measured: -7 % on the JVP kernels, -3 % on the plain stats pass, 0 on plain apply
     RowW<T, JVP, K32> rw;
-    constexpr int S_VMEM = MODE == 1 ? RPW * (JVP ? 2 : 1) : 0;   // stores between a DMA request and its wait
+    // stores between a DMA request and its wait (statistics mode: the n1 / 1-sigma stores, out of bounds when not asked for)
+    constexpr int S_VMEM = MODE == 1 ? RPW * (JVP ? 2 : 1) : RPW * 2;
+    __amdgpu_buffer_rsrc_t rs_n1 = make_rsrc(nullptr, 0), rs_r1 = make_rsrc(nullptr, 0);
 
     int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
     int64_t t1 = t0 + a.geo.chunk < a.geo.total ? t0 + a.geo.chunk : a.geo.total;
@@ -783,6 +784,11 @@ cnx_fwd_kernel(FwdArgs a) {
             if (rcur >= 0) flush_stats(rcur);
             rcur = r;
             rw.set(l.wc0, w.bc, a.sc, a.sh, a.scd, a.shd, r, q, lane);
+            if constexpr (MODE == 0) {
+                // (empty resources when the caller does not keep n1: every store is then dropped by the hardware)
+                rs_n1 = make_rsrc(a.n1_out ? (const T*)a.n1_out + r * img : nullptr, a.n1_out ? (uint32_t)(img * sizeof(T)) : 0u);
+                rs_r1 = make_rsrc(a.rho1_out ? a.rho1_out + r * (img / 16) : nullptr, a.rho1_out ? (uint32_t)(img / 16 * sizeof(float)) : 0u);
+            }
             if constexpr (MODE == 1) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -818,29 +824,6 @@ cnx_fwd_kernel(FwdArgs a) {
         // Tile rows below the image (only in the last row of tiles: s % 16 of its 16 rows exist) are skipped -- nothing
         // of them is stored or summed.  nrows is wave-uniform.
         const int nrows = ABL_NO_CHAIN ? 0 : rows_in_image(s, y0 + wave * RPW);
-#if MFC_CNX_EXP & 2
-        if constexpr (MODE == 0 && !JVP) {
-            // experiment: two independent tile rows per iteration (the compiler interleaves the two chains)
-#pragma unroll 1
-            for (int ri = 0; ri < RPW; ri += 2) {
-                const int y = wave * RPW + ri;
-                const int gy = y0 + y;
-                if (gy >= s) continue;
-                const bool ok0 = gx < s, ok1 = gy + 1 < s && gx < s;
-                RowFwd<T, JVP> f0, f1;
-                chain_row<T, JVP, false, K32>(tile, tiled, l.wc0, w, rw, border, gy, gx, s, y, q, m, lane, f0);
-                chain_row<T, JVP, false, K32>(tile, tiled, l.wc0, w, rw, border, gy + 1, gx, s, y + 1, q, m, lane, f1);
-                if (ok0) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) s1[j] = fma4(f0.g[j], f0.g[j], s1[j]);
-                }
-                if (ok1) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) s1[j] = fma4(f1.g[j], f1.g[j], s1[j]);
-                }
-            }
-        } else
-#endif
 #pragma unroll 1
         for (int ri = 0; ri < nrows; ++ri) {
             const int y = wave * RPW + ri;
@@ -856,6 +839,12 @@ cnx_fwd_kernel(FwdArgs a) {
                         if constexpr (JVP) s2[j] = fma4(f.g[j], f.gd[j], s2[j]);
                     }
                 }
+                // n1 = LN(conv(FiLM(h1))) exactly as the expansion consumed it, and its 1/sigma: the apply pass and the
+                // reverse kernels start from these instead of repeating the conv and the LayerNorm (cnx_*_n1 kernels)
+                const uint32_t pix = (uint32_t)(gy * s + gx);
+                buf_st_frag(rs_n1, ok ? (uint32_t)((pix * 16 + 4 * q) * sizeof(T)) : BUF_OOB, f.n1f);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, f.rho1), rs_r1,
+                                                      (ok && q == 0) ? pix * 4u : BUF_OOB, 0, 0);
             } else {
                 f32x4 p1 = ld_f32x4(w.bp), p1d = z4;
 #pragma unroll
@@ -893,13 +882,18 @@ cnx_fwd_kernel(FwdArgs a) {
                 }
             }
         }
-        if constexpr (MODE == 1) {
+        {
             // the skipped rows' stores are still issued, steered out of bounds: the wait below counts them (vmcnt note)
             const float zv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int ri = nrows; ri < RPW; ++ri) {
-                buf_st4(rs_o, BUF_OOB, zv, (const T*)nullptr);
-                if constexpr (JVP) buf_st4(rs_od, BUF_OOB, zv, (const T*)nullptr);
+                if constexpr (MODE == 1) {
+                    buf_st4(rs_o, BUF_OOB, zv, (const T*)nullptr);
+                    if constexpr (JVP) buf_st4(rs_od, BUF_OOB, zv, (const T*)nullptr);
+                } else {
+                    buf_st4(rs_n1, BUF_OOB, zv, (const T*)nullptr);
+                    __builtin_amdgcn_raw_buffer_store_b32(0u, rs_r1, BUF_OOB, 0, 0);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1483,6 +1477,346 @@ cnx_bwd_conv_kernel(BwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// "From n1" kernels.  The statistics pass can keep n1 = LN(conv3x3(FiLM(h1))) -- the 16-channel map the expansion
+// consumes -- and its 1/sigma (mfc_cnx_stats_save).  Everything downstream of n1 is PER PIXEL (1x1 convs, GELU, GRN,
+// layer scale, residual), so the apply pass and the two reverse kernels that used to repeat the conv and the
+// LayerNorm become plain streaming kernels: no halo, no LDS tiles, no DMA, no workgroup barrier in the loop.  A wave
+// owns 16 consecutive pixels of the flattened image per step; the MFMA B-operand fragment of lane (q, m) -- channels
+// 4q..4q+3 of pixel m -- is exactly the 8 (bf16) / 16 (fp32) bytes at that pixel, so the fragments come straight from
+// buffer loads (512 / 1024 contiguous bytes per wave instruction), prefetched one step ahead.
+// Unit of work: one "step" = 64 consecutive pixels of one image (16 per wave); an image has spi = ceil(s*s / 64)
+// steps (the last one partly out of bounds: those lanes load zeros and store nowhere); a workgroup walks a
+// contiguous range of steps.  Per-row (r) sums are flushed when the range crosses into the next image, exactly like
+// the tile kernels (same record layout, same fixed-order reduce kernels).
+// ---------------------------------------------------------------------------
+inline Geo make_pix_geo(int64_t R, int s, int64_t maxBlocks, int64_t& grid) {
+    Geo g;
+    g.R = R; g.s = s; g.tilesX = 0; g.tilesY = 0;
+    g.tilesPerImg = ((int64_t)s * s + 63) / 64;          // steps per image
+    g.total = R * g.tilesPerImg;
+    grid = g.total < maxBlocks ? g.total : maxBlocks;
+    g.chunk = (g.total + grid - 1) / grid;
+    grid = (g.total + g.chunk - 1) / g.chunk;
+    g.kmax = (int)((g.chunk + g.tilesPerImg - 2) / g.tilesPerImg) + 1;
+    return g;
+}
+
+struct PixArgs {
+    Geo geo;
+    const void* n1; const float* rho1; const void* h1; const void* dout;
+    const float* sc; const float* sh;
+    Dev p;
+    const float* q; const float* kG;
+    void* o; void* dc1;
+    float* ws;
+};
+
+// expansion + GELU of one wave row from its n1 fragment (the tail of chain_row)
+template <typename T, bool WG>
+__device__ inline void expand_gelu(const FwdW<T>& w, const typename Frag<T>::type& n1f, f32x4 g[2], f32x4 gp[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        f32x4 e = ld_f32x4(w.be[j]);
+        mma16(e, w.we[j], n1f);
+        if constexpr (WG) gelu_both4(e, g[j], gp[j]);
+        else g[j] = gelu4(e);
+    }
+}
+
+// MODE 1 of cnx_fwd_kernel from n1: o = (Wp^T (gelu(We^T n1 + be) (gamma + q) + beta) + bp) * ls + (1 + scale) h1 + shift
+template <typename T>
+__global__ void __launch_bounds__(NT, sizeof(T) == 2 ? 4 : 1)
+cnx_apply_n1_kernel(PixArgs a) {
+    typedef typename Frag<T>::type frag_t;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, m = lane & 15;
+    FwdW<T> w;
+    w.load(a.p, q, m);
+    const int s = a.geo.s;
+    const int64_t npix = (int64_t)s * s, img = npix * 16, spi = a.geo.tilesPerImg;
+    const int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
+    const int64_t t1 = t0 + a.geo.chunk < a.geo.total ? t0 + a.geo.chunk : a.geo.total;
+    if (t0 >= t1) return;
+    int64_t r = t0 / spi;
+    int64_t j = t0 - r * spi;
+    int64_t rcur = -1;
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 gq[2] = {z4, z4}, sc14 = z4, sh4 = z4;
+    __amdgpu_buffer_rsrc_t rs_o = make_rsrc(nullptr, 0);
+    auto off_of = [&](int64_t jj) -> uint32_t {
+        const int64_t px = (jj * 4 + wave) * 16 + m;
+        return px < npix ? (uint32_t)((px * 16 + 4 * q) * sizeof(T)) : BUF_OOB;
+    };
+    auto fetch = [&](int64_t rr, int64_t jj, frag_t& n, frag_t& h) {
+        const uint32_t off = off_of(jj);
+        n = buf_ld_frag(make_rsrc((const T*)a.n1 + rr * img, (uint32_t)(img * sizeof(T))), off, (const T*)nullptr);
+        h = buf_ld_frag(make_rsrc((const T*)a.h1 + rr * img, (uint32_t)(img * sizeof(T))), off, (const T*)nullptr);
+    };
+    frag_t nn, hn;
+    fetch(r, j, nn, hn);
+    for (int64_t t = t0; t < t1; ++t) {
+        const frag_t n1f = nn, h1f = hn;
+        land(n1f); land(h1f);
+        const int64_t rt = r, jt = j;
+        if (++j == spi) { j = 0; ++r; }
+        if (rt != rcur) {
+            rcur = rt;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gq[jj][i] = a.q[rt * 32 + 16 * jj + 4 * q + i] + w.gam[jj][i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sc14[i] = 1.0f + a.sc[rt * 16 + 4 * q + i];
+                sh4[i] = a.sh[rt * 16 + 4 * q + i];
+            }
+            land(gq[0]); land(gq[1]); land(sc14); land(sh4);
+            rs_o = make_rsrc((const T*)a.o + rt * img, (uint32_t)(img * sizeof(T)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // next step's operands (past the end: this step again -- the instruction count stays fixed)
+        if (t + 1 < t1) fetch(r, j, nn, hn); else fetch(rt, jt, nn, hn);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 g[2], gp[2];
+        expand_gelu<T, false>(w, n1f, g, gp);
+        f32x4 p1 = ld_f32x4(w.bp);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            frag_t yf;
+            const f32x4 yv = fma4(g[jj], gq[jj], ld_f32x4(w.bet[jj]));
+            make_frag(yf, yv[0], yv[1], yv[2], yv[3]);
+            mma16(p1, w.wp[jj], yf);
+        }
+        float hv[4], ov[4];
+        unfrag(h1f, hv);
+        const f32x4 o4 = fma4(p1, ld_f32x4(w.ls), fma4(sc14, ld_f32x4(hv), sh4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ov[i] = o4[i];
+        buf_st4(rs_o, off_of(jt), ov, (const T*)nullptr);
+    }
+}
+
+// MODE 0 / MODE 1 of cnx_bwd_kernel from n1 (and, MODE 1, its 1/sigma rho1)
+template <typename T, int MODE>
+__global__ void __launch_bounds__(NT, sizeof(T) == 2 ? (MODE == 0 ? 4 : 3) : 1)
+cnx_bwd_n1_kernel(PixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename Frag<T>::type frag_t;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, m = lane & 15;
+    // LDS: per wave [6][16][CS] transpose scratch (MODE 1), then the cross-wave flush scratch
+    T* wsT = reinterpret_cast<T*>(smem) + (size_t)wave * WS_TILES * 16 * CS;
+    float* red = reinterpret_cast<float*>(smem + (((size_t)NWAVES * WS_TILES * 16 * CS * sizeof(T)) + 15) / 16 * 16);
+    FwdW<T> w;
+    w.load(a.p, q, m);
+    const T* pw = (const T*)a.p.con_w;  // [32][16]: dy[e] = sum_c Wp[e][c] dp1[c]
+    frag_t wpT[2] = {load_bfrag<T>(pw, 1, 16, 0, 0, q, m), load_bfrag<T>(pw, 1, 16, 0, 16, q, m)};
+    const T* ew = (const T*)a.p.exp_w;  // [16][32]: dn1[c] = sum_e We[c][e] de[e]
+    frag_t weT[2] = {load_bfrag<T>(ew, 1, 32, 0, 0, q, m), load_bfrag<T>(ew, 1, 32, 16, 0, q, m)};
+    land(wpT[0]); land(wpT[1]); land(weT[0]); land(weT[1]);
+    const int s = a.geo.s;
+    const int64_t npix = (int64_t)s * s, img = npix * 16, spi = a.geo.tilesPerImg;
+    const int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
+    const int64_t t1 = t0 + a.geo.chunk < a.geo.total ? t0 + a.geo.chunk : a.geo.total;
+    int64_t r = t0 < t1 ? t0 / spi : 0;
+    int64_t j = t0 < t1 ? t0 - r * spi : 0;
+    int64_t rcur = -1;
+    float gq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, kg[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float dqp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 aWp[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, aWe[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    float dls[4] = {0.f, 0.f, 0.f, 0.f};
+    float dbe[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    __amdgpu_buffer_rsrc_t rs_dc = make_rsrc(nullptr, 0);
+    int krow = 0;
+    auto flush_row = [&]() {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = red_m(dqp[jj][i]);
+                    if (m == 0) red[wave * REC_DQ + 16 * jj + 4 * q + i] = v;
+                    dqp[jj][i] = 0.f;
+                }
+            __syncthreads();
+            if (threadIdx.x < REC_DQ) {       // fixed order: wave 0 + wave 1 + wave 2 + wave 3
+                const int c = threadIdx.x;
+                const float v = ((red[c] + red[REC_DQ + c]) + red[2 * REC_DQ + c]) + red[3 * REC_DQ + c];
+                a.ws[((int64_t)blockIdx.x * a.geo.kmax + krow) * REC_DQ + c] = v;
+            }
+            ++krow;
+            __syncthreads();
+        }
+    };
+    auto off_of = [&](int64_t jj) -> uint32_t {
+        const int64_t px = (jj * 4 + wave) * 16 + m;
+        return px < npix ? (uint32_t)((px * 16 + 4 * q) * sizeof(T)) : BUF_OOB;
+    };
+    auto roff_of = [&](int64_t jj) -> uint32_t {
+        const int64_t px = (jj * 4 + wave) * 16 + m;
+        return px < npix ? (uint32_t)(px * 4) : BUF_OOB;
+    };
+    auto fetch = [&](int64_t rr, int64_t jj, frag_t& n, frag_t& d, float& rho) {
+        const uint32_t off = off_of(jj);
+        n = buf_ld_frag(make_rsrc((const T*)a.n1 + rr * img, (uint32_t)(img * sizeof(T))), off, (const T*)nullptr);
+        d = buf_ld_frag(make_rsrc((const T*)a.dout + rr * img, (uint32_t)(img * sizeof(T))), off, (const T*)nullptr);
+        if constexpr (MODE == 1)
+            rho = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                      make_rsrc(a.rho1 + rr * npix, (uint32_t)(npix * sizeof(float))), roff_of(jj), 0, 0));
+    };
+    frag_t nn, dn;
+    float rn = 0.f;
+    if (t0 < t1) fetch(r, j, nn, dn, rn);
+    for (int64_t t = t0; t < t1; ++t) {
+        const frag_t n1f = nn, dof = dn;
+        const float rho1 = rn;
+        land(n1f); land(dof);
+        if constexpr (MODE == 1) land(rho1);
+        const int64_t rt = r, jt = j;
+        if (++j == spi) { j = 0; ++r; }
+        if (rt != rcur) {
+            if (rcur >= 0) flush_row();
+            rcur = rt;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    gq[jj][i] = a.q[rt * 32 + 16 * jj + 4 * q + i] + w.gam[jj][i];
+                    if constexpr (MODE == 1) kg[jj][i] = a.kG[rt * 32 + 16 * jj + 4 * q + i];
+                }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { land(gq[jj][i]); if constexpr (MODE == 1) land(kg[jj][i]); }
+            if constexpr (MODE == 1) rs_dc = make_rsrc((const T*)a.dc1 + rt * img, (uint32_t)(img * sizeof(T)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < t1) fetch(r, j, nn, dn, rn); else fetch(rt, jt, nn, dn, rn);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t goff = off_of(jt);
+        const bool ok = goff != BUF_OOB;
+        float dov[4];
+        unfrag(dof, dov);                                   // zero outside the image
+        f32x4 g[2], gp[2];
+        expand_gelu<T, MODE == 1>(w, n1f, g, gp);
+        float dp1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dp1[i] = dov[i] * w.ls[i];
+        frag_t dp1f;
+        make_frag(dp1f, dp1[0], dp1[1], dp1[2], dp1[3]);
+        f32x4 dy[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            dy[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma16(dy[jj], wpT[jj], dp1f);      // dy^T = Wp dp1^T
+        }
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dqp[jj][i] += dy[jj][i] * g[jj][i];
+        } else {
+            float n1[4];
+            unfrag(n1f, n1);
+            float yv[2][4];
+            f32x4 p1 = f32x4{w.bp[0], w.bp[1], w.bp[2], w.bp[3]};
+            frag_t yf[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) yv[jj][i] = g[jj][i] * gq[jj][i] + w.bet[jj][i];
+                make_frag(yf[jj], yv[jj][0], yv[jj][1], yv[jj][2], yv[jj][3]);
+            }
+            mma_pair(p1, w.wp[0], w.wp[1], yf[0], yf[1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dls[i] += dov[i] * p1[i];
+            frag_t def[2];
+            f32x4 dn1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                float de[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float dg = dy[jj][i] * gq[jj][i] + g[jj][i] * kg[jj][i];
+                    de[i] = ok ? dg * gp[jj][i] : 0.f;
+                    dbe[jj][i] += de[i];
+                }
+                make_frag(def[jj], de[0], de[1], de[2], de[3]);
+            }
+            mma_pair(dn1, weT[0], weT[1], def[0], def[1]);      // dn1^T = We de^T
+            float dnv[4] = {dn1[0], dn1[1], dn1[2], dn1[3]}, dc[4];
+            ln_bwd_a(dnv, n1, rho1, dc);
+            buf_st4(rs_dc, goff, dc, (const T*)nullptr);
+            // weight gradients contract over the 16 pixels of the wave row: one batched transpose through the wave scratch
+            *reinterpret_cast<frag_t*>(wsT + (0 * 16 + m) * CS + 4 * q) = yf[0];
+            *reinterpret_cast<frag_t*>(wsT + (1 * 16 + m) * CS + 4 * q) = yf[1];
+            *reinterpret_cast<frag_t*>(wsT + (2 * 16 + m) * CS + 4 * q) = dp1f;
+            *reinterpret_cast<frag_t*>(wsT + (3 * 16 + m) * CS + 4 * q) = n1f;     // (rows outside the image meet de = 0)
+            *reinterpret_cast<frag_t*>(wsT + (4 * 16 + m) * CS + 4 * q) = def[0];
+            *reinterpret_cast<frag_t*>(wsT + (5 * 16 + m) * CS + 4 * q) = def[1];
+            lds_fence();
+            const frag_t tdp = pix_k_frag<T>(wsT + 2 * 16 * CS, q, m);
+            const frag_t tn1 = pix_k_frag<T>(wsT + 3 * 16 * CS, q, m);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const frag_t ty = pix_k_frag<T>(wsT + jj * 16 * CS, q, m);
+                const frag_t tde = pix_k_frag<T>(wsT + (4 + jj) * 16 * CS, q, m);
+                mma16(aWp[jj], ty, tdp);    // [e][c] += y^T dp1
+                mma16(aWe[jj], tn1, tde);   // [c][e] += n1^T de
+            }
+            lds_fence();
+        }
+    }
+    if (rcur >= 0) flush_row();
+    if constexpr (MODE == 0) {
+        // records this workgroup's range did not reach: zeros (the row reduction only reads the ones it did reach, but
+        // a fresh workspace must never leak into a sum if the geometry changes)
+        for (int k = krow; k < a.geo.kmax; ++k)
+            if (threadIdx.x < REC_DQ) a.ws[((int64_t)blockIdx.x * a.geo.kmax + k) * REC_DQ + threadIdx.x] = 0.f;
+    }
+    if constexpr (MODE == 1) {
+        float* scratch = red;   // con_w [32][16] | exp_w [16][32] | ls [16] | exp_b [32]
+        float vls[4], vbe[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vls[i] = red_m(dls[i]);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) vbe[jj][i] = red_m(dbe[jj][i]);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < REC_MAIN; i += NT) scratch[i] = 0.f;
+        __syncthreads();
+        for (int wv = 0; wv < NWAVES; ++wv) {
+            if (wave == wv) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        scratch[(16 * jj + 4 * q + e) * 16 + m] += aWp[jj][e];
+                        scratch[512 + (4 * q + e) * 32 + 16 * jj + m] += aWe[jj][e];
+                    }
+                if (m == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        scratch[1024 + 4 * q + i] += vls[i];
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) scratch[1040 + 16 * jj + 4 * q + i] += vbe[jj][i];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        float* rec = a.ws + (int64_t)blockIdx.x * REC_MAIN;
+        for (int i = threadIdx.x; i < REC_MAIN; i += NT) rec[i] = ABL_NO_FLUSH ? 0.f : scratch[i];
+    }
+}
+template <typename T> inline size_t lds_bwd_n1_bytes() {
+    return (((size_t)NWAVES * WS_TILES * 16 * CS * sizeof(T)) + 15) / 16 * 16 + (size_t)REC_MAIN * sizeof(float);
+}
+
+// ---------------------------------------------------------------------------
 // fixed-order reductions of the workspace records
 // ---------------------------------------------------------------------------
 // Per-row quantities: out0[r][c] (c < n0) / out1[r][c - n0] (c >= n0) = sum over the workgroups b whose tile range
@@ -1649,8 +1983,10 @@ inline bool params_ok(const mfc_cnx_params* p) {
 // 2048 for every kernel before): 4-per-CU kernels 3 rounds (-7..-11 %), the 3-per-CU tangent statistics 3 rounds
 // (-8 %), the 2-per-CU kernels exactly one round (-3..-7 %); the conv-gradient kernel, three per CU since its dout
 // tile became compact and single-buffered, one round of 768 (-7 % against two per CU).  MFC_CNX_MAX_BLOCKS / mfc_cnx_max_blocks override all.
-enum CnxKind { K_STATS = 0, K_APPLY, K_STATS_JVP, K_APPLY_JVP, K_BWD_STATS, K_BWD_MAIN, K_BWD_CONV, K_NKIND };
-static const int64_t DEFAULT_BLOCKS[K_NKIND] = {3072, 3072, 2304, 512, 3072, 512, 768};
+enum CnxKind { K_STATS = 0, K_APPLY, K_STATS_JVP, K_APPLY_JVP, K_BWD_STATS, K_BWD_MAIN, K_BWD_CONV, K_APPLY_N1, K_BWD_STATS_N1,
+               K_BWD_MAIN_N1, K_NKIND };
+static const int64_t DEFAULT_BLOCKS[K_NKIND] = {3072, 3072, 2304, 512, 3072, 512, 768, 3072, 3072, 2304};
+inline bool kind_is_pix(int k) { return k >= K_APPLY_N1; }
 static int64_t MAX_BLOCKS = getenv("MFC_CNX_MAX_BLOCKS") ? atoll(getenv("MFC_CNX_MAX_BLOCKS")) : 0;   // 0: per-kernel defaults
 inline int64_t max_blocks(CnxKind k) { return MAX_BLOCKS > 0 ? MAX_BLOCKS : DEFAULT_BLOCKS[k]; }
 constexpr int MAX_S = 8000;   // one [s, s, 16] fp32 image must stay below the 4 GiB a buffer resource addresses
@@ -1691,7 +2027,7 @@ int fwd_launch(bool jvp, int mode, const FwdArgs& a, int64_t grid, hipStream_t s
 int fwd_common(int dtype, int mode, int64_t R, int s, const void* h0, const void* h0dot,
                const float* scale, const float* shift, const float* scaledot, const float* shiftdot,
                const mfc_cnx_params* p, float* S1, float* S2, const float* q, const float* qdot,
-               void* o, void* odot, float* ws, void* stream) {
+               void* o, void* odot, float* ws, void* stream, void* n1_out = nullptr, float* rho1_out = nullptr) {
     if (!h0 || !scale || !shift || !params_ok(p)) return MFC_EFAULT;
     if (R <= 0 || s <= 0) return MFC_EINVAL;
     if (s > MAX_S) return MFC_ENOSYS;
@@ -1705,6 +2041,7 @@ int fwd_common(int dtype, int mode, int64_t R, int s, const void* h0, const void
     a.geo = make_geo(R, s, max_blocks(mode == 0 ? (jvp ? K_STATS_JVP : K_STATS) : (jvp ? K_APPLY_JVP : K_APPLY)), grid);
     a.h0 = h0; a.h0d = h0dot; a.sc = scale; a.sh = shift; a.scd = scaledot; a.shd = shiftdot;
     a.p = to_dev(p); a.S1 = S1; a.S2 = S2; a.q = q; a.qd = qdot; a.o = o; a.od = odot; a.ws = ws;
+    a.n1_out = n1_out; a.rho1_out = rho1_out;
     hipStream_t st = (hipStream_t)stream;
     int rc = dtype == MFC_F32 ? fwd_launch<float>(jvp, mode, a, grid, st) : fwd_launch<u16>(jvp, mode, a, grid, st);
     if (!rc && mode == 0) rc = reduce_rows(ws, a.geo, REC_STATS, 0, jvp ? 64 : 32, 32, S1, S2, st);
@@ -1721,11 +2058,75 @@ extern "C" int mfc_cnx_stats(int dtype, int64_t R, int s, const void* h1, const 
                       nullptr, nullptr, ws, stream);
 }
 
+extern "C" int mfc_cnx_stats_save(int dtype, int64_t R, int s, const void* h1, const void* h1dot,
+                                  const float* scale, const float* shift, const float* scaledot,
+                                  const float* shiftdot, const mfc_cnx_params* p, float* S1, float* S2,
+                                  float* ws, void* n1_out, float* rho1_out, void* stream) {
+    if (!n1_out || !rho1_out) return MFC_EFAULT;
+    return fwd_common(dtype, 0, R, s, h1, h1dot, scale, shift, scaledot, shiftdot, p, S1, S2, nullptr, nullptr,
+                      nullptr, nullptr, ws, stream, n1_out, rho1_out);
+}
+
+namespace {
+inline int pix_common(int dtype, int64_t R, int s) {
+    if (R <= 0 || s <= 0 || (dtype != MFC_F32 && dtype != MFC_BF16)) return MFC_EINVAL;
+    if (s > MAX_S) return MFC_ENOSYS;
+    return MFC_OK;
+}
+}  // namespace
+
+extern "C" int mfc_cnx_apply_n1(int dtype, int64_t R, int s, const void* n1, const void* h1, const float* scale,
+                                const float* shift, const mfc_cnx_params* p, const float* q, void* o, void* stream) {
+    if (!n1 || !h1 || !scale || !shift || !params_ok(p) || !q || !o) return MFC_EFAULT;
+    if (int rc = pix_common(dtype, R, s)) return rc;
+    PixArgs a = {};
+    int64_t grid;
+    a.geo = make_pix_geo(R, s, max_blocks(K_APPLY_N1), grid);
+    a.n1 = n1; a.h1 = h1; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.q = q; a.o = o;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == MFC_F32 ? launch_k(cnx_apply_n1_kernel<float>, grid, 0, st, a) : launch_k(cnx_apply_n1_kernel<u16>, grid, 0, st, a);
+}
+
+extern "C" int mfc_cnx_bwd_stats_n1(int dtype, int64_t R, int s, const void* n1, const mfc_cnx_params* p, const float* q,
+                                    const void* dout, float* dq, float* ws, void* stream) {
+    if (!n1 || !params_ok(p) || !q || !dout || !dq || !ws) return MFC_EFAULT;
+    if (int rc = pix_common(dtype, R, s)) return rc;
+    PixArgs a = {};
+    int64_t grid;
+    a.geo = make_pix_geo(R, s, max_blocks(K_BWD_STATS_N1), grid);
+    a.n1 = n1; a.dout = dout; a.p = to_dev(p); a.q = q; a.ws = ws;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = dtype == MFC_F32 ? launch_k(cnx_bwd_n1_kernel<float, 0>, grid, lds_bwd_n1_bytes<float>(), st, a)
+                              : launch_k(cnx_bwd_n1_kernel<u16, 0>, grid, lds_bwd_n1_bytes<u16>(), st, a);
+    if (!rc) rc = reduce_rows(ws, a.geo, REC_DQ, 0, 32, 32, dq, nullptr, st);
+    return rc;
+}
+
+extern "C" int mfc_cnx_bwd_main_n1(int dtype, int64_t R, int s, const void* n1, const float* rho1, const mfc_cnx_params* p,
+                                   const float* q, const float* kG, const void* dout, void* dc1, const mfc_cnx_grads* g,
+                                   float* ws, void* stream) {
+    if (!n1 || !rho1 || !params_ok(p) || !q || !kG || !dout || !dc1 || !g || !ws) return MFC_EFAULT;
+    if (!g->con_w || !g->ls || !g->exp_w || !g->exp_b) return MFC_EFAULT;
+    if (int rc = pix_common(dtype, R, s)) return rc;
+    PixArgs a = {};
+    int64_t grid;
+    a.geo = make_pix_geo(R, s, max_blocks(K_BWD_MAIN_N1), grid);
+    a.n1 = n1; a.rho1 = rho1; a.dout = dout; a.p = to_dev(p); a.q = q; a.kG = kG; a.dc1 = dc1; a.ws = ws;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = dtype == MFC_F32 ? launch_k(cnx_bwd_n1_kernel<float, 1>, grid, lds_bwd_n1_bytes<float>(), st, a)
+                              : launch_k(cnx_bwd_n1_kernel<u16, 1>, grid, lds_bwd_n1_bytes<u16>(), st, a);
+    if (!rc) {
+        RedSegs sg = {{{g->con_w, 0, 512}, {g->exp_w, 512, 1024}, {g->ls, 1024, 1040}, {g->exp_b, 1040, 1072}}, 4};
+        rc = reduce_blocks(ws, grid, REC_MAIN, REC_MAIN, sg, st);
+    }
+    return rc;
+}
+
 extern "C" int64_t mfc_cnx_ws_elems(int64_t R, int s) {
     if (R <= 0 || s <= 0 || s > MAX_S) return -1;
     int64_t n = 0;
     for (int k = 0; k < K_NKIND; ++k) {
-        const int64_t e = ws_elems_for(R, s, max_blocks((CnxKind)k));
+        const int64_t e = ws_elems_for(R, s, max_blocks((CnxKind)k), kind_is_pix(k));
         n = e > n ? e : n;
     }
     return n;

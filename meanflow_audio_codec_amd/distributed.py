@@ -26,16 +26,19 @@ first; each leaves an event in ``state.work.pending`` and the next step's forwar
 two steps; AdamW writes its bf16 slice straight into the working copy and the all-gather runs in place on it.
 
 Precision of the exchange: the big kernels' gradients are stored, and summed across ranks, in bf16 (RCCL adds in
-fp32 inside one reduction step but every hop of the ring re-rounds the running sum to bf16: relative error
-<= ~log2(G) * 2^-9 of the summed gradient, the same order as the bf16 rounding of each rank's own contribution; the
-AdamW update normalises gradient magnitudes, so this noise moves an update by a fraction of lr).  Small leaves and the
-ConvNeXt interior's gradients are exchanged in fp32.
+fp32 inside one reduction step but every hop of the ring re-rounds the running sum to bf16).  With u = 2^-8 (half a
+bf16 ulp) and A = sum over ranks of |contribution|: worst case (G - 1) u A per element, RMS about sqrt(G - 1) times the
+single rounding an fp32 exchange into the same bf16 buffer would make -- the same order as the bf16 rounding of each
+rank's own contribution (``tests/test_bench_launcher.py::test_bf16_exchange_error_bound`` measures both exchanges
+against the exact sum at G = 4 and 8).  The AdamW update normalises gradient magnitudes, so this noise moves an update
+by that fraction of lr.  Small leaves and the ConvNeXt interior's gradients are exchanged in fp32.
 
 Which collective is used (native ``reduce_scatter_tensor`` / ``all_gather_into_tensor`` or their all-reduce /
-all-gather emulation) is decided ONCE in ``__init__`` -- by backend, confirmed by a tiny probe collective whose verdict
-is min-reduced over the ranks -- so every rank always issues the same sequence of collectives.  Errors after that
-propagate (a rank that fails exits non-zero and the launcher tears the job down) instead of silently switching one
-rank to a different collective, which would hang its peers.
+all-gather emulation) is decided ONCE in ``__init__`` from the backend and the environment alone -- no collective is
+involved in the decision, so it cannot itself desynchronise the ranks -- and every rank then issues the same sequence
+of collectives.  Errors propagate (a rank that fails exits non-zero and the launcher tears the job down) instead of
+silently switching one rank to a different collective, which would hang its peers.  Constructing a ``GradReducer`` is
+therefore NOT a collective; using it is (every rank must make the same calls in the same order).
 """
 from __future__ import annotations
 
@@ -74,33 +77,15 @@ class GradReducer:
         self._native = self._decide_native()                 # reduce_scatter_tensor / all_gather_into_tensor
 
     def _decide_native(self) -> bool:
-        """Taken once, identically on every rank: native tensor collectives on RCCL, the emulation elsewhere (gloo has
-        no reduce-scatter).  ``MFC_DIST_NATIVE=0/1`` overrides the backend rule.  On a CUDA device the choice is
-        confirmed by running both collectives once on 64 floats; every rank contributes its verdict to a MIN
-        all-reduce, so one rank's failure moves ALL ranks to the emulation -- before any training traffic."""
+        """Taken once, identically on every rank and WITHOUT a collective: a pure function of the backend (RCCL has
+        ``reduce_scatter_tensor`` / ``all_gather_into_tensor``; gloo has no reduce-scatter and takes the emulation) and
+        of ``MFC_DIST_NATIVE=0/1``, which must be set alike on all ranks (the launcher hands one environment to every
+        rank).  There is deliberately no probe: a probe collective that raises on one rank only would leave that rank
+        in a different collective from its peers (a hang).  If a native collective fails later, the error propagates,
+        the rank exits non-zero and the launcher tears the job down."""
         env = os.environ.get("MFC_DIST_NATIVE")
         native = (dist.get_backend(self.group) == "nccl") if env is None else (env == "1")
-        if not native or self.world == 1:
-            return False
-        ok = 1
-        dev = torch.device("cuda", torch.cuda.current_device())
-        try:
-            full = torch.ones(64 * self.world, dtype=torch.float32, device=dev)
-            out = torch.empty(64, dtype=torch.float32, device=dev)
-            dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_gather_into_tensor(full, out, group=self.group)
-            torch.cuda.synchronize(dev)
-            if not bool((full == float(self.world)).all().item()):
-                ok = 0
-        except (RuntimeError, AttributeError, NotImplementedError, ValueError, TypeError) as e:
-            print(f"[mfc] rank {self.rank}: native reduce-scatter / all-gather probe failed ({e})", flush=True)
-            ok = 0
-        verdict = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=self.group)     # plain all-reduce: exists on every backend
-        native = bool(verdict.item())
-        if not native and self.rank == 0:
-            print("[mfc] sharded optimizer uses all_reduce / all_gather (native tensor collectives unavailable)", flush=True)
-        return native
+        return bool(native) and self.world > 1
 
     # ---- sharded optimizer ------------------------------------------------------------------------------------
     def _buf(self, key, n, dtype, device):

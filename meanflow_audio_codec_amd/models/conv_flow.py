@@ -19,6 +19,7 @@ created at init time when ``latent_input_dim`` is given (defect 12).
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -30,7 +31,8 @@ BOTTLENECK = 128  # models/conv_flow.py:142,153
 
 class ConvCtx:
     """Saved primal activations of one forward pass (consumed by ``backward``)."""
-    __slots__ = ("R", "x_in", "a1", "g1", "a2", "g2", "H0", "rho", "O", "G", "q", "sc", "sh", "cond", "lat", "enc")
+    __slots__ = ("R", "x_in", "a1", "g1", "a2", "g2", "H0", "rho", "O", "G", "q", "sc", "sh", "cond", "lat", "enc", "N1",
+                 "rho1")
 
     def __init__(self):
         for k in self.__slots__:
@@ -59,6 +61,9 @@ class ConditionalConvFlow:
         # proj/mnist_trial feeds [B, 32, latent] (:163-166).  latent_proj is sized for what is fed.
         self.latent_input_dim = latent_dimension if latent_input_dim is None else latent_input_dim
         self.dtype = dtype
+        # keep n1 = LN(conv(FiLM(h1))) of the statistics pass for the apply and reverse passes (streaming kernels instead
+        # of a second / third / fourth conv + LayerNorm); costs one more [R, S] map per saved block
+        self.keep_n1 = os.environ.get("MFC_CNX_KEEP_N1", "1") != "0"
         self._ws = {}
         self._block_names = [self.block_param_names(i) for i in range(num_blocks)]
 
@@ -184,6 +189,7 @@ class ConditionalConvFlow:
         assert n_tan <= R
         Rt = R + n_tan
         K, S, s, dev, T = self.num_blocks, self.S, self.spatial_size, x.device, self.dtype
+        keep_n1 = self.use_grn and self.keep_n1
         X = self._buf(("X0", Rt), (Rt, D), T, dev) if not save else torch.empty((Rt, D), dtype=T, device=dev)
         X[:R].copy_(x)
         if n_tan:
@@ -203,10 +209,18 @@ class ConditionalConvFlow:
             ctx.H0 = self._buf(("H0save", R, n_tan), (K * R + n_tan, S), T, dev)    # holds h1 = LN(h0) (primal rows)
             ctx.O = self._buf(("Osave", R, n_tan), (K * R + n_tan, S), T, dev)
             ctx.rho = self._buf(("rhosave", R), (K, R, S // 16), torch.float32, dev)
+            if keep_n1:
+                # n1 = LN(conv(FiLM(h1))) and its 1/sigma of every block's primal rows, written by the statistics pass:
+                # the apply pass and the reverse pass start from them (ops.cnx_forward keep= / cnx_backward n1=)
+                ctx.N1 = self._buf(("N1save", R), (K * R, S), T, dev)
+                ctx.rho1 = self._buf(("rho1save", R), (K, R, S // 16), torch.float32, dev)
         else:
             H0s = self._buf(("H0", Rt), (Rt, S), T, dev)
             Os = self._buf(("O", Rt), (Rt, S), T, dev)
             rhos = self._buf(("rho", R), (R, S // 16), torch.float32, dev)
+            if keep_n1:
+                N1s = self._buf(("N1", R), (R, S), T, dev)
+                rho1s = self._buf(("rho1", R), (R, S // 16), torch.float32, dev)
         for i in range(K):
             b = f"blocks_{i}"
             a1 = dense(X, w[f"{b}/input_proj1/kernel"], w[f"{b}/input_proj1/bias"], bias_rows=R)
@@ -222,15 +236,21 @@ class ConditionalConvFlow:
             sc, sh = cp[:R, :16].contiguous(), cp[:R, 16:].contiguous()
             cw = self._cnx_w(w, i)
             Gs, qs = [], []
+            if keep_n1:
+                N1 = ctx.N1[i * R:(i + 1) * R] if save else N1s
+                r1 = (ctx.rho1[i] if save else rho1s).view(R, -1)
+                keep = lambda a, b: (N1[a:b], r1[a:b])
+            else:
+                keep = lambda a, b: None
             if n_tan:
                 scd, shd = cp[R:, :16].contiguous(), cp[R:, 16:].contiguous()
                 _, _, G, q = ops.cnx_forward(H0[:n_tan], sc[:n_tan], sh[:n_tan], cw, s, h0dot=H0[R:],
                                              scaledot=scd, shiftdot=shd, out=O[:n_tan], outdot=O[R:],
-                                             use_grn=self.use_grn)
+                                             use_grn=self.use_grn, keep=keep(0, n_tan) if save else None)
                 Gs.append(G); qs.append(q)
             if R > n_tan:
                 _, _, G, q = ops.cnx_forward(H0[n_tan:R], sc[n_tan:], sh[n_tan:], cw, s, out=O[n_tan:R],
-                                             use_grn=self.use_grn)
+                                             use_grn=self.use_grn, keep=keep(n_tan, R))
                 Gs.append(G); qs.append(q)
             a2 = dense(O, w[f"{b}/output_proj1/kernel"], w[f"{b}/output_proj1/bias"], bias_rows=R)
             g2 = ops.gelu_fwd(a2, act_rows=R)
@@ -291,8 +311,9 @@ class ConditionalConvFlow:
             cg = self._cnx_g(grads, i)
             for t_ in cg.values():
                 t_.zero_()
+            n1kw = {} if ctx.N1 is None else dict(n1=ctx.N1[i * R:(i + 1) * R], rho1=ctx.rho1[i])
             _, dsc, dsh = ops.cnx_backward(H0, ctx.sc[i], ctx.sh[i], self._cnx_w(w, i), s, ctx.G[i], ctx.q[i], dO, cg,
-                                           dh0=dH0, scratch=dC1, rho0=ctx.rho[i], use_grn=self.use_grn)
+                                           dh0=dH0, scratch=dC1, rho0=ctx.rho[i], use_grn=self.use_grn, **n1kw)
             dcp = torch.cat([dsc, dsh], 1).contiguous()
             dense_dw(ctx.cond, dcp, out=grads[f"{b}/conditioning_layer/kernel"])
             ops.colsum(dcp, out=grads[f"{b}/conditioning_layer/bias"])

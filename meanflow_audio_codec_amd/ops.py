@@ -154,10 +154,14 @@ def cnx_workspace(R: int, s: int, device) -> torch.Tensor:
 
 
 def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, shiftdot=None, out=None,
-                outdot=None, use_grn: bool = True):
+                outdot=None, use_grn: bool = True, keep=None):
     """o = ConvNeXtBlock(FiLM(h1)) on [R, s, s, 16] where ``h0`` holds h1 = LN(h0) and ``h0dot`` the
     tangent of that LayerNorm (see ln16 / ln16_jvp, or the MFC_GEMM_LN16 / LN16T epilogue);
-    returns (o, odot, G, q).  Runs mfc_cnx_stats -> mfc_grn_finalize -> mfc_cnx_apply."""
+    returns (o, odot, G, q).  Runs mfc_cnx_stats -> mfc_grn_finalize -> mfc_cnx_apply.
+
+    ``keep = (n1, rho1)`` (buffers [R, s, s, 16] in h0's dtype and fp32 [R, s, s]): the statistics pass writes
+    n1 = LN(conv(FiLM(h1))) and its 1/sigma there (``mfc_cnx_stats_save``); a primal-only call then applies from n1
+    (``mfc_cnx_apply_n1``: no second conv / LayerNorm), and ``cnx_backward(.., n1=, rho1=)`` can start from them too."""
     _lib.require_cuda(h0)
     R = h0.shape[0]
     dt = _lib.dtype_code(h0.dtype)
@@ -177,10 +181,21 @@ def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, sh
     G = torch.empty((R, 32), dtype=torch.float32, device=dev)
     q = torch.empty_like(G)
     qd = torch.empty_like(G) if jvp else None
-    if use_grn:
+    if keep is not None and not use_grn:
+        raise _lib.MfcError("keep=(n1, rho1) needs the statistics pass (use_grn=True)")
+    if keep is not None:
+        n1, rho1 = keep
+        assert n1.shape == h0.shape and n1.dtype == h0.dtype and n1.is_contiguous()
+        assert rho1.dtype == torch.float32 and rho1.is_contiguous() and rho1.numel() == R * s * s
+        _lib.check(L.mfc_cnx_stats_save(dt, R, s, h0.data_ptr(), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
+                                        _lib.ptr(scaledot), _lib.ptr(shiftdot), ctypes.byref(ps), S[0].data_ptr(),
+                                        S[1].data_ptr() if jvp else None, ws.data_ptr(), n1.data_ptr(), rho1.data_ptr(), st),
+                   "mfc_cnx_stats_save")
+    elif use_grn:
         _lib.check(L.mfc_cnx_stats(dt, R, s, h0.data_ptr(), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
                                    _lib.ptr(scaledot), _lib.ptr(shiftdot), ctypes.byref(ps), S[0].data_ptr(),
                                    S[1].data_ptr() if jvp else None, ws.data_ptr(), st), "mfc_cnx_stats")
+    if use_grn:
         _lib.check(L.mfc_grn_finalize(R, S[0].data_ptr(), S[1].data_ptr() if jvp else None, G.data_ptr(),
                                       q.data_ptr(), _lib.ptr(qd), st), "mfc_grn_finalize")
     else:
@@ -191,6 +206,10 @@ def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, sh
             qd.zero_()
     o = out if out is not None else torch.empty_like(h0)
     od = (outdot if outdot is not None else torch.empty_like(h0)) if jvp else None
+    if keep is not None and not jvp:
+        _lib.check(L.mfc_cnx_apply_n1(dt, R, s, keep[0].data_ptr(), h0.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                      ctypes.byref(ps), q.data_ptr(), o.data_ptr(), st), "mfc_cnx_apply_n1")
+        return o, od, G, q
     _lib.check(L.mfc_cnx_apply(dt, R, s, h0.data_ptr(), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
                                _lib.ptr(scaledot), _lib.ptr(shiftdot), ctypes.byref(ps), q.data_ptr(),
                                _lib.ptr(qd), o.data_ptr(), _lib.ptr(od), st), "mfc_cnx_apply")
@@ -198,10 +217,12 @@ def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, sh
 
 
 def cnx_backward(h0, scale, shift, w: dict, s: int, G, q, dout, grads: dict, dh0=None, scratch=None, rho0=None,
-                 use_grn: bool = True):
+                 use_grn: bool = True, n1=None, rho1=None):
     """Backward of cnx_forward's primal (``h0`` = h1 = LN(h0), ``rho0`` its 1/sigma): returns
     (dh0, dscale, dshift) with dh0 the gradient w.r.t. the RAW h0 (LayerNorm backward included);
-    accumulates (+=) the small-parameter gradients into the fp32 tensors of ``grads``."""
+    accumulates (+=) the small-parameter gradients into the fp32 tensors of ``grads``.
+    ``n1``, ``rho1`` (what ``cnx_forward(.., keep=)`` kept): the first two passes start from them
+    (``mfc_cnx_bwd_stats_n1`` / ``mfc_cnx_bwd_main_n1``) instead of repeating the conv and the LayerNorm."""
     assert rho0 is not None and rho0.dtype == torch.float32 and rho0.is_contiguous()
     _lib.require_cuda(h0, dout)
     R = h0.shape[0]
@@ -217,18 +238,31 @@ def cnx_backward(h0, scale, shift, w: dict, s: int, G, q, dout, grads: dict, dh0
     dq = torch.empty((R, 32), dtype=torch.float32, device=dev)
     kG = torch.empty_like(dq)
     ws = cnx_workspace(R, s, dev)
-    if use_grn:
+    from_n1 = n1 is not None
+    if from_n1:
+        assert rho1 is not None and n1.shape == h0.shape and n1.dtype == h0.dtype and n1.is_contiguous()
+        assert rho1.dtype == torch.float32 and rho1.is_contiguous() and rho1.numel() == R * s * s
+    if use_grn and from_n1:
+        _lib.check(L.mfc_cnx_bwd_stats_n1(dt, R, s, n1.data_ptr(), ctypes.byref(ps), q.data_ptr(), dout.data_ptr(),
+                                          dq.data_ptr(), ws.data_ptr(), st), "mfc_cnx_bwd_stats_n1")
+    elif use_grn:
         _lib.check(L.mfc_cnx_bwd_stats(dt, R, s, h0.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctypes.byref(ps),
                                        q.data_ptr(), dout.data_ptr(), dq.data_ptr(), ws.data_ptr(), st),
                    "mfc_cnx_bwd_stats")
+    if use_grn:
         _lib.check(L.mfc_grn_bwd_finalize(R, G.data_ptr(), dq.data_ptr(), kG.data_ptr(),
                                           grads["grn_gamma"].data_ptr(), st), "mfc_grn_bwd_finalize")
     else:
         kG.zero_()          # no GRN: d g = d y (gamma + q) + g kG with gamma = 1, q = 0, kG = 0
     dc1 = scratch if scratch is not None else torch.empty_like(h0)
-    _lib.check(L.mfc_cnx_bwd_main(dt, R, s, h0.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctypes.byref(ps),
-                                  q.data_ptr(), kG.data_ptr(), dout.data_ptr(), dc1.data_ptr(), ctypes.byref(gs),
-                                  ws.data_ptr(), st), "mfc_cnx_bwd_main")
+    if from_n1:
+        _lib.check(L.mfc_cnx_bwd_main_n1(dt, R, s, n1.data_ptr(), rho1.data_ptr(), ctypes.byref(ps), q.data_ptr(),
+                                         kG.data_ptr(), dout.data_ptr(), dc1.data_ptr(), ctypes.byref(gs), ws.data_ptr(), st),
+                   "mfc_cnx_bwd_main_n1")
+    else:
+        _lib.check(L.mfc_cnx_bwd_main(dt, R, s, h0.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctypes.byref(ps),
+                                      q.data_ptr(), kG.data_ptr(), dout.data_ptr(), dc1.data_ptr(), ctypes.byref(gs),
+                                      ws.data_ptr(), st), "mfc_cnx_bwd_main")
     if dh0 is None:
         dh0 = torch.empty_like(h0)
     dsc = torch.empty((R, 16), dtype=torch.float32, device=dev)

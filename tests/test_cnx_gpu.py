@@ -37,7 +37,10 @@ def _rel(a, b):
     return ((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-CASES = [(3, 20), (1, 16), (2, 37), (2, 530), (2, 520)]   # (2, 520): 33 x 33 tiles, a workgroup spans two rows r
+# (2, 520): 33 x 33 tiles, a workgroup spans two rows r.  (1, 626), (2, 626): the LITERAL spatial size of BASELINE config #4
+# (s = floor(sqrt(392704)); 40 x 40 = 1600 tiles per image, the geometry the persistent grids are tuned on; the last tile
+# row / column holds 2 of 16 image rows / columns, so the below-the-image row skip and the border DMA path both run)
+CASES = [(3, 20), (1, 16), (2, 37), (2, 530), (2, 520), (1, 626), (2, 626)]
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 4e-2)])
@@ -110,6 +113,64 @@ def test_backward(dtype, tol, R, s):
 
 
 @pytest.mark.parametrize("dtype,tol,btol", [(torch.float32, 2e-5, 5e-5), (torch.bfloat16, 4e-2, 6e-2)])
+@pytest.mark.parametrize("R,s", CASES)
+def test_kept_n1_paths(dtype, tol, btol, R, s):
+    """The statistics pass keeps n1 = LN(conv(FiLM(h1))) and its 1/sigma (mfc_cnx_stats_save); the apply pass
+    (mfc_cnx_apply_n1) and the first two reverse passes (mfc_cnx_bwd_stats_n1 / mfc_cnx_bwd_main_n1) start from them:
+    the forward result is BIT-identical to the h1-based kernels (the expansion consumed exactly this n1), every
+    gradient matches the fp64 oracle at the tolerance of the h1-based path."""
+    from meanflow_audio_codec_amd import ops
+    p, h0, sc, sh, g = _setup(R, s, seed=7)
+    dout = torch.randn(h0.shape, generator=g, dtype=torch.float64)
+    h0q = h0.to(dtype).double().requires_grad_(True)
+    doutq = dout.to(dtype).double()
+    pq = fo.tree_map(lambda t: t.clone(), p)
+    if dtype == torch.bfloat16:
+        for k in ("Conv_0", "Conv_1", "Conv_2"):
+            pq[k]["kernel"] = p[k]["kernel"].to(dtype).double()
+    pq = fo.tree_map(lambda t: t.requires_grad_(True), pq)
+    scq, shq = sc.clone().requires_grad_(True), sh.clone().requires_grad_(True)
+    o_ref = _oracle(pq, h0q, scq, shq)
+    flat = fo.flatten(pq)
+    names = list(flat)
+    grads = torch.autograd.grad((o_ref * doutq).sum(), [h0q, scq, shq] + [flat[n] for n in names])
+    gref = dict(zip(["h0", "sc", "sh"] + names, grads))
+
+    w = _weights(p, dtype)
+    f32 = lambda t: t.float().contiguous().cuda()
+    h1, rho = ops.ln16(h0.to(dtype).cuda())
+    o_old, _, G_old, q_old = ops.cnx_forward(h1, f32(sc), f32(sh), w, s)
+    n1 = torch.full_like(h1, float("nan"))
+    rho1 = torch.full((R, s, s), float("nan"), dtype=torch.float32, device="cuda")
+    o, _, G, q = ops.cnx_forward(h1, f32(sc), f32(sh), w, s, keep=(n1, rho1))
+    assert torch.isfinite(n1.float()).all() and torch.isfinite(rho1).all() and (rho1 > 0).all()
+    assert torch.equal(G, G_old) and torch.equal(q, q_old)
+    assert torch.equal(o, o_old), (o.float() - o_old.float()).abs().max().item()
+    assert _rel(o, o_ref.detach()) < tol
+    # the tangent statistics pass keeps the same n1 (primal rows)
+    h0d = torch.randn(h0.shape, generator=g, dtype=torch.float64)
+    h1d = ops.ln16_jvp(h1, rho, h0d.to(dtype).cuda())
+    n1b, rho1b = torch.zeros_like(n1), torch.zeros_like(rho1)
+    ops.cnx_forward(h1, f32(sc), f32(sh), w, s, h0dot=h1d, scaledot=f32(0.1 * sc), shiftdot=f32(0.1 * sh), keep=(n1b, rho1b))
+    assert torch.equal(n1b, n1) and torch.equal(rho1b, rho1)
+    # reverse pass from n1
+    gacc = {k: torch.zeros(v.shape, dtype=torch.float32, device="cuda") for k, v in w.items()}
+    dh0, dsc, dsh = ops.cnx_backward(h1, f32(sc), f32(sh), w, s, G, q, dout.to(dtype).cuda(), gacc, rho0=rho, n1=n1, rho1=rho1)
+    checks = {
+        "h0": (dh0, gref["h0"]), "sc": (dsc, gref["sc"]), "sh": (dsh, gref["sh"]),
+        "conv_w": (gacc["conv_w"], gref["Conv_0/kernel"]), "conv_b": (gacc["conv_b"], gref["Conv_0/bias"]),
+        "exp_w": (gacc["exp_w"], gref["Conv_1/kernel"].reshape(16, 32)), "exp_b": (gacc["exp_b"], gref["Conv_1/bias"]),
+        "gamma": (gacc["grn_gamma"], gref["GlobalResponseNormalization_0/gamma"]),
+        "beta": (gacc["grn_beta"], gref["GlobalResponseNormalization_0/beta"]),
+        "con_w": (gacc["con_w"], gref["Conv_2/kernel"].reshape(32, 16)), "con_b": (gacc["con_b"], gref["Conv_2/bias"]),
+        "ls": (gacc["ls"], gref["layer_scale_gamma"]),
+    }
+    errs = {k: _rel(a, b) for k, (a, b) in checks.items()}
+    bad = {k: v for k, v in errs.items() if not v < btol}
+    assert not bad, errs
+
+
+@pytest.mark.parametrize("dtype,tol,btol", [(torch.float32, 2e-5, 5e-5), (torch.bfloat16, 4e-2, 6e-2)])
 def test_few_persistent_workgroups(dtype, tol, btol):
     """7 workgroups walk all 3 x 9 tiles: every one crosses tile rows, image rows r, both DMA buffers and flushes its
     per-r accumulators several times -- same results as the oracle."""
@@ -118,5 +179,6 @@ def test_few_persistent_workgroups(dtype, tol, btol):
     try:
         test_forward_and_jvp(dtype, tol, 3, 37)
         test_backward(dtype, btol, 3, 37)
+        test_kept_n1_paths(dtype, tol, btol, 3, 37)
     finally:
         _lib.lib().mfc_cnx_max_blocks(old)

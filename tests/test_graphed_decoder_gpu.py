@@ -70,6 +70,9 @@ def test_graph_replay_equals_eager_and_oracle(n_steps):
     # fresh noise: a different clip, and the noise stream advances by B rows per call
     a2 = dec(fresh_noise=True).clone()
     assert not torch.equal(dec.eps, eps) and (a2 - a1).abs().max().item() > 1e-3
+    # the draw is a node of the graph: replay k decodes rows [k B, (k + 1) B) of the Philox stream (a1b re-used call 0)
+    assert dec.noise_in_graph and dec.calls == 2
+    assert torch.equal(eps, dec.noise_of_call(0)) and torch.equal(dec.eps, dec.noise_of_call(1))
     _, audio_ref2 = _oracle_audio(pq, dec.eps, lat, n_steps)
     assert np.abs(a2.double().cpu().numpy() - audio_ref2).max() / np.abs(audio_ref2).max() < 2e-4
 
@@ -85,3 +88,80 @@ def test_graphed_decoder_bf16_and_token_output():
     ref = fo.one_step_decode(fo.conv_flow_apply, pq, dec.eps.bfloat16().double().cpu(), lat.double())
     assert ((x0.double().cpu() - ref).abs().max() / ref.abs().max()).item() < 5e-2
     assert torch.equal(dec(fresh_noise=False), x0)
+
+
+def test_capture_survives_pending_garbage_that_owns_device_resources():
+    """Regression for the abort of round 2 ("Fatal Python error: Aborted ... Garbage-collecting" inside
+    ``torch.cuda.graph``): the cyclic collector ran during stream capture and destroyed an unrelated object that owned
+    HIP resources.  Here the trigger is built deterministically -- an UNREACHABLE reference cycle that owns an older,
+    instantiated hipGraph and an event, still uncollected, with the collector's threshold at 1 so that the very next
+    allocations would start a collection -- and fifty more such cycles become unreachable INSIDE the capture (at the
+    first kernel call of the captured body).  ``GraphedDecoder`` collects before the capture and keeps the collector off
+    during it, so the cycles die outside the capture: before it (the old one) and after it (the new ones)."""
+    import gc
+    import weakref
+
+    from meanflow_audio_codec_amd import ops
+    from meanflow_audio_codec_amd.evaluators import GraphedDecoder
+    model, state, pq, lat, cfg = _setup()
+
+    class Holder:
+        pass
+
+    def make_cycle():
+        h = Holder()
+        h.me = h                                   # reference cycle: only the cyclic collector can free it
+        h.event = torch.cuda.Event()
+        h.event.record()
+        return h
+
+    old = make_cycle()
+    old.graph = torch.cuda.CUDAGraph()
+    buf = torch.zeros(16, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.graph(old.graph):
+        buf.add_(1.0)
+    old.graph.replay()
+    torch.cuda.synchronize()
+    alive = weakref.ref(old)
+    gc.collect()
+    was = gc.get_threshold()
+    inside = []
+    real = ops.randn_dev
+    state_in_capture = {}
+
+    # cycles with recorded events (and one more instantiated graph), kept alive until the capture is under way
+    pool = [make_cycle() for _ in range(50)]
+    pool[0].graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(pool[0].graph):
+        buf.add_(2.0)
+    torch.cuda.synchronize()
+    inside.extend(weakref.ref(h) for h in pool)
+
+    def spy(*a, **kw):
+        if torch.cuda.is_current_stream_capturing() and pool:
+            state_in_capture["gc_enabled"] = gc.isenabled()
+            pool.clear()                           # 50 unreachable cycles owning device resources, DURING the capture
+            junk = [[i] for i in range(2000)]      # allocations: far beyond a threshold of 1, were the collector on
+            del junk
+            state_in_capture["collected_inside"] = sum(r() is None for r in inside)
+        return real(*a, **kw)
+
+    try:
+        gc.disable()
+        del old                                    # now unreachable and uncollected
+        assert alive() is not None
+        gc.set_threshold(1, 1, 1)
+        gc.enable()
+        ops.randn_dev = spy
+        dec = GraphedDecoder(model, state.work, B, lat.cuda(), n_steps=0, token_shape=(NF, N), mdct_config=cfg, seed=1)
+    finally:
+        ops.randn_dev = real
+        gc.set_threshold(*was)
+        gc.enable()
+    assert alive() is None                                         # collected by the constructor, before the capture
+    assert state_in_capture == {"gc_enabled": False, "collected_inside": 0}
+    gc.collect()
+    assert all(r() is None for r in inside)                        # ... and the capture-time garbage afterwards
+    a = dec().clone()
+    assert torch.isfinite(a).all() and torch.equal(dec(fresh_noise=False), a)

@@ -73,3 +73,39 @@ def test_mnist_mdct_shape_runs():
     tokens = tok.tokenize(x).reshape(8, -1)
     state, loss, key = train_step(state, PRNGKey(1), tokens, MeanFlowLoss())
     assert torch.isfinite(loss).item() and state.step == 1
+
+
+def test_config3_real_dimensions_vs_oracle():
+    """BASELINE config #3 at its REAL dimensions (configs/method=mean_flow--architecture=mlp_mixer--dataset=mnist--
+    tokenization=mdct.json; reference models/mlp_mixer.py:171-323 defaults): D = 1024 -> nt = 1024 tokens x 16 channels,
+    token / channel mixing dims 2048 / 2048, 8 blocks, cond 128, latent 256, 32 latent + 512 context tokens
+    (303.8 M parameters), fp32, B = 4: MeanFlow loss (JVP through the mixer and its encoder) and the
+    gradients of every leaf against the fp64 oracle."""
+    from meanflow_audio_codec_amd.models import ConditionalMLPMixerFlow, TrainState, adamw
+    from meanflow_audio_codec_amd.preprocessing import MDCTTokenization
+    from meanflow_audio_codec_amd.trainers import MeanFlowLoss, PRNGKey
+    D, CD, LAT, NB, B = 1024, 128, 256, 8, 4
+    model = ConditionalMLPMixerFlow(D, CD, NB, LAT, dtype=torch.float32)            # every other argument: the defaults
+    shapes = fo.mixer_flow_shapes(D, CD, LAT, NB)                                    # oracle defaults = reference defaults
+    p64 = fo.init_params(shapes, seed=11, special=False)
+    flat = {k: v.float().cuda().contiguous() for k, v in fo.flatten(p64).items()}
+    assert {k: tuple(v.shape) for k, v in flat.items()} == {k: tuple(v) for k, v in model.param_shapes().items()}
+    n_params = sum(v.numel() for v in flat.values())
+    # SURVEY 8(d) quotes 303.8 M for the flow itself; the MLPMixerEncoder wired to `encode` adds D x 512 x 256 + its block
+    assert n_params > 303e6
+    state = TrainState.create(apply_fn=model.apply, params=flat, tx=adamw(1e-4, 1e-4), model=model)
+    pq = fo.unflatten({k: state.work[k].double().cpu() for k in flat})
+    g = torch.Generator().manual_seed(21)
+    img = torch.rand(B, 784, generator=g)
+    x = MDCTTokenization(512, 256).tokenize(img.cuda()).reshape(B, -1)                # the config's own tokens: [B, 2, 512]
+    assert x.shape == (B, D)
+    e = torch.randn(B, D, generator=g)
+    t, r = fo.sample_tr_from_normals(torch.randn(B, 1, generator=g, dtype=torch.float64),
+                                     torch.randn(B, 1, generator=g, dtype=torch.float64))
+    loss_ref, g_ref, _ = fo.mf_loss(fo.mixer_flow_apply, fo.mixer_encode, pq, x.double().cpu(), e.double(), t, r)
+    loss, grads = MeanFlowLoss().compute_loss(state, PRNGKey(0), x, e=e.cuda(), t=t.float().cuda(), r=r.float().cuda())
+    assert abs(loss.item() - loss_ref.item()) < 2e-4 * max(1.0, abs(loss_ref.item()))
+    gr = fo.flatten(g_ref)
+    errs = {k: _rel(grads[k], gr[k]) for k in gr if gr[k].abs().max() > 0}
+    bad = {k: v for k, v in errs.items() if not v < 3e-3}
+    assert len(errs) > 100 and not bad, bad
