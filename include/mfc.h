@@ -41,7 +41,7 @@ extern "C" {
  * of mfc_sample_tr and mfc_flow_prepare, caller-owned workspaces instead of atomics (mfc_gemm_ws_elems,
  * mfc_cnx_ws_elems, MFC_FLOW_LOSS_WS_PER_ROW), colsum output of mfc_gemm_adamw.  Version 3 (round 3): additions only --
  * mfc_randn_dev (noise draw as a graph node); mfc_cnx_stats_save / mfc_cnx_apply_n1 / mfc_cnx_bwd_stats_n1 /
- * mfc_cnx_bwd_main_n1 (ConvNeXt passes from a kept n1). */
+ * mfc_cnx_bwd_main_n1 (ConvNeXt passes from a kept n1); mfc_colsum_tall / mfc_colsum_ws_elems. */
 #define MFC_ABI_VERSION 3
 int mfc_abi_version(void);
 const char* mfc_build_info(void);
@@ -323,6 +323,12 @@ int mfc_flow_loss(int dtype, int kind, int mode, int64_t B, int64_t Bglobal, int
 /* out[N] (fp32) = (accumulate ? out : 0) + scale * sum_rows X[M,N]  -- bias gradients */
 int mfc_colsum(int dtype, int64_t M, int64_t N, const void* X, int64_t ld, float scale, float* out,
                int accumulate, void* stream);
+/* The same for tall matrices (M >= 2048 rows, N a multiple of 16 bytes of `dtype`, 16-byte aligned rows): two fixed-order
+ * stages over a caller workspace of mfc_colsum_ws_elems(dtype, M, N) floats (0: shape not taken -> MFC_ENOSYS, use
+ * mfc_colsum).  Bias gradients of the Mixer's per-token Dense layers (models/mlp_mixer.py:66-94), M = B * tokens. */
+int64_t mfc_colsum_ws_elems(int dtype, int64_t M, int64_t N);
+int mfc_colsum_tall(int dtype, int64_t M, int64_t N, const void* X, int64_t ld, float scale, float* out,
+                    int accumulate, float* ws, void* stream);
 
 /* out = a x + b y (y may be NULL) -- Heun update, evaluators/sampling.py:84 */
 int mfc_axpby(int dtype, int64_t n, float a, const void* x, float b, const void* y, void* out,

@@ -94,6 +94,8 @@ SIGNATURES = {
     "mfc_flow_loss": (c_int, [c_int, c_int, c_int, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, _P,
                               c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "mfc_colsum": (c_int, [c_int, c_int64, c_int64, _P, c_int64, c_float, _P, c_int, _P]),
+    "mfc_colsum_ws_elems": (c_int64, [c_int, c_int64, c_int64]),
+    "mfc_colsum_tall": (c_int, [c_int, c_int64, c_int64, _P, c_int64, c_float, _P, c_int, _P, _P]),
     "mfc_axpby": (c_int, [c_int, c_int64, c_float, _P, c_float, _P, _P, _P]),
     "mfc_cast": (c_int, [c_int, c_int, c_int64, _P, _P, _P]),
     "mfc_adamw": (c_int, [c_int, c_int64, _P, _P, _P, c_float, _P, _P, c_float, c_float, c_float, c_float,

@@ -514,6 +514,106 @@ extern "C" int mfc_flow_loss(int dtype, int kind, int mode, int64_t B, int64_t B
     return mfc_launch_status();
 }
 
+// Tall matrices (M in the 10^5 of the Mixer's [B * tokens, C] activations): the column-parallel kernels above would
+// leave all but a few CUs idle and walk M rows serially.  Two fixed-order stages instead: workgroup (chunk, colgroup)
+// sums its rows of its 16-byte column groups -- threads [tr][tc], tr strides the rows, the tr partials are added in
+// tr order through LDS -- into partial[chunk][N]; the second kernel adds the chunks in order.  Bitwise reproducible.
+template <typename T, int VW>
+__global__ void __launch_bounds__(ET) colsum_tall_kernel(int64_t M, int64_t N, const T* X, int64_t ld, int tcols, int64_t mchunk,
+                                                         float* partial) {
+    typedef T vt __attribute__((ext_vector_type(VW)));
+    __shared__ float red[ET * VW];
+    const int tc = threadIdx.x % tcols, tr = threadIdx.x / tcols, trows = ET / tcols;
+    const int64_t cg = blockIdx.x * (int64_t)tcols + tc;                 // 16-byte column group
+    const int64_t m0 = blockIdx.y * mchunk, m1 = m0 + mchunk < M ? m0 + mchunk : M;
+    float acc[VW];
+#pragma unroll
+    for (int i = 0; i < VW; ++i) acc[i] = 0.f;
+    if (cg * VW < N) {
+        const T* p = X + cg * VW;
+        int64_t m = m0 + tr;
+        for (; m + 3 * trows < m1; m += 4 * trows) {                      // four rows in flight
+            vt v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const vt*>(p + (m + u * trows) * ld);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < VW; ++i) { T e = v[u][i]; acc[i] += St<T>::ld(&e); }
+        }
+        for (; m < m1; m += trows) {
+            const vt v = *reinterpret_cast<const vt*>(p + m * ld);
+#pragma unroll
+            for (int i = 0; i < VW; ++i) { T e = v[i]; acc[i] += St<T>::ld(&e); }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VW; ++i) red[(tr * tcols + tc) * VW + i] = acc[i];
+    __syncthreads();
+    if (tr == 0 && cg * VW < N) {
+#pragma unroll
+        for (int i = 0; i < VW; ++i) {
+            float sum = red[tc * VW + i];
+            for (int k = 1; k < trows; ++k) sum += red[(k * tcols + tc) * VW + i];
+            partial[blockIdx.y * N + cg * VW + i] = sum;
+        }
+    }
+}
+__global__ void __launch_bounds__(ET) colsum_chunks_kernel(int64_t nchunk, int64_t N, const float* partial, float scale, float* out,
+                                                           int accum) {
+    const int64_t c = blockIdx.x * (int64_t)ET + threadIdx.x;
+    if (c >= N) return;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int64_t k = 0;
+    for (; k + 3 < nchunk; k += 4) {
+        v0 += partial[k * N + c]; v1 += partial[(k + 1) * N + c]; v2 += partial[(k + 2) * N + c]; v3 += partial[(k + 3) * N + c];
+    }
+    for (; k < nchunk; ++k) v0 += partial[k * N + c];
+    const float acc = ((v0 + v1) + (v2 + v3)) * scale;
+    out[c] = accum ? out[c] + acc : acc;
+}
+namespace {
+struct TallPlan { int vw, tcols; int64_t cgroups, nchunk, mchunk; };
+inline bool tall_plan(int dtype, int64_t M, int64_t N, TallPlan& t) {
+    t.vw = dtype == MFC_F32 ? 4 : 8;
+    if (N % t.vw || M < 2048) return false;
+    const int64_t groups = N / t.vw;
+    t.tcols = groups >= 64 ? 64 : (groups >= 32 ? 32 : (groups >= 16 ? 16 : (groups >= 8 ? 8 : (groups >= 4 ? 4 : (groups >= 2 ? 2 : 1)))));
+    t.cgroups = ceil_div64(groups, t.tcols);
+    const int trows = ET / t.tcols;
+    int64_t nchunk = ceil_div64(2048, t.cgroups);                      // ~8 workgroups per CU in total
+    const int64_t most = ceil_div64(M, (int64_t)trows * 8);              // at least 8 row sweeps per workgroup
+    if (nchunk > most) nchunk = most;
+    if (nchunk < 1) nchunk = 1;
+    t.mchunk = ceil_div64(M, nchunk);
+    t.nchunk = ceil_div64(M, t.mchunk);
+    return true;
+}
+}  // namespace
+
+extern "C" int64_t mfc_colsum_ws_elems(int dtype, int64_t M, int64_t N) {
+    TallPlan t;
+    if (M <= 0 || N <= 0 || !DT_OK(dtype)) return -1;
+    return tall_plan(dtype, M, N, t) ? t.nchunk * N : 0;
+}
+
+extern "C" int mfc_colsum_tall(int dtype, int64_t M, int64_t N, const void* X, int64_t ld, float scale, float* out,
+                               int accumulate, float* ws, void* stream) {
+    if (!X || !out || !ws) return MFC_EFAULT;
+    if (M <= 0 || N <= 0 || ld < N || !DT_OK(dtype)) return MFC_EINVAL;
+    TallPlan t;
+    const size_t es = dtype == MFC_F32 ? 4 : 2;
+    if (!tall_plan(dtype, M, N, t) || (ld * es) % 16 != 0 || ((uintptr_t)X % 16) != 0 || t.nchunk > 65535) return MFC_ENOSYS;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)t.cgroups, (unsigned)t.nchunk);
+    if (dtype == MFC_F32)
+        hipLaunchKernelGGL((colsum_tall_kernel<float, 4>), grid, dim3(ET), 0, st, M, N, (const float*)X, ld, t.tcols, t.mchunk, ws);
+    else
+        hipLaunchKernelGGL((colsum_tall_kernel<u16, 8>), grid, dim3(ET), 0, st, M, N, (const u16*)X, ld, t.tcols, t.mchunk, ws);
+    hipLaunchKernelGGL(colsum_chunks_kernel, dim3((unsigned)ceil_div64(N, ET)), dim3(ET), 0, st, t.nchunk, N, ws, scale, out, accumulate);
+    return mfc_launch_status();
+}
+
 extern "C" int mfc_colsum(int dtype, int64_t M, int64_t N, const void* X, int64_t ld, float scale, float* out,
                           int accumulate, void* stream) {
     if (!X || !out) return MFC_EFAULT;

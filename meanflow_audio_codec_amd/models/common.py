@@ -68,8 +68,12 @@ def auto_splitk(M: int, N: int, K: int) -> int:
     two workgroups per CU -- measured optimum at K = 392 704 and K = 6 270 016 (tools/sweep_splitk.py: 256..512 slices
     are 6-12 % faster than 1024, whose 64 MB of slabs per operand-GB start to show, and than 128, which starves HBM)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if K < 2048 or tiles >= 256:
+    if K < 512 or tiles >= 256:
         return 1
+    if K < 2048:
+        # the small validation nets (BASELINE configs #2 / #3: a handful of output tiles, K ~ 1000): spread the tiles'
+        # K range over the chip, at least 128 deep per slice -- one 128 x 128 fp32 tile per CU on 9 of 256 CUs otherwise
+        return max(1, min(K // 128, (512 + tiles - 1) // tiles))
     target = 512 if tiles <= 2 else (1024 + tiles - 1) // tiles
     return max(1, min((K + 255) // 256, target))
 
@@ -91,5 +95,5 @@ def dense_dx(dy, w, *, alpha=1.0, residual=None, beta=1.0, out=None):
 
 
 def dense_dw(x, dy, *, alpha=1.0, out=None):
-    """dw [K,N] = x [M,K]^T @ dy [M,N]."""
-    return ops.gemm(x, dy, trans_a=True, alpha=alpha, out=out, splitk=1)
+    """dw [K,N] = x [M,K]^T @ dy [M,N] (contraction over the M rows: split when the output has few tiles)."""
+    return ops.gemm(x, dy, trans_a=True, alpha=alpha, out=out, splitk=auto_splitk(x.shape[1], dy.shape[1], x.shape[0]))

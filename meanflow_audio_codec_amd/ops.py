@@ -313,6 +313,14 @@ def colsum(X, scale=1.0, out=None, accumulate=False):
     assert X.stride(1) == 1
     if out is None:
         out = torch.empty(N, dtype=torch.float32, device=X.device)
+    dt = _lib.dtype_code(X.dtype)
+    need = int(_lib.lib().mfc_colsum_ws_elems(dt, M, N)) if M >= 2048 else 0
+    if need > 0 and (X.stride(0) * X.element_size()) % 16 == 0 and X.data_ptr() % 16 == 0:
+        # tall activations (the Mixer's [B * tokens, C] maps): row-parallel two-stage sum, fixed order
+        ws = torch.empty(need, dtype=torch.float32, device=X.device)
+        _lib.check(_lib.lib().mfc_colsum_tall(dt, M, N, X.data_ptr(), X.stride(0), float(scale), out.data_ptr(),
+                                              int(accumulate), ws.data_ptr(), _lib.stream_ptr()), "mfc_colsum_tall")
+        return out
     _lib.check(_lib.lib().mfc_colsum(_lib.dtype_code(X.dtype), M, N, X.data_ptr(), X.stride(0), float(scale),
                                      out.data_ptr(), int(accumulate), _lib.stream_ptr()), "mfc_colsum")
     return out

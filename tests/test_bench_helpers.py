@@ -42,7 +42,8 @@ def test_auto_splitk_is_a_pure_function_of_the_shape():
     from meanflow_audio_codec_amd.models.common import auto_splitk
     S, D = 6270016, 392704
     assert auto_splitk(128, 128, S) == 512 and auto_splitk(192, 128, S) == 512 and auto_splitk(64, 128, D) == 512
-    assert auto_splitk(128, 128, 1000) == 1                      # short K: no split
+    assert auto_splitk(128, 128, 400) == 1                       # short K: no split
+    assert auto_splitk(128, 1040, 1040) == 8 and auto_splitk(128, 128, 1000) == 7   # small nets: >= 128 deep per slice
     assert auto_splitk(128, 128, 4096) == 16                     # never more slices than 256-deep chunks
     assert auto_splitk(128, S, 128) == 1 and auto_splitk(4096, 8192, 100000) == 1   # plenty of output tiles already
     assert auto_splitk(384, 128, S) == (1024 + 2) // 3          # three tiles: ~1024 workgroups in total
