@@ -582,14 +582,8 @@ def run_convflow(args):
 
         def mse(st, key):
             aux = {}
-            strat.compute_loss(st, key, tok.tokenize(clips).reshape(B, -1), aux=aux, **rows)
-            v = round(float(aux["per_example"].mean().item()) / D, 4)
-            if use_fuse:
-                # this un-fused evaluation materialised the big kernels' gradient buffers (2 B / parameter), which the
-                # fused schedule of the timed steps never touches: give them back
-                st._grads = None
-                torch.cuda.empty_cache()
-            return v
+            strat.compute_loss(st, key, tok.tokenize(clips).reshape(B, -1), aux=aux, want_grads=False, **rows)
+            return round(float(aux["per_example"].mean().item()) / D, 4)
         return one_step, mse
 
     def timed_leg(B, warmup, steps, state, key, profile):
@@ -942,7 +936,7 @@ def learn_probe(state, model, tok, wl, B, D, device, strat, steps=20, lr=1e-7):
 
     def mse():
         aux = {}
-        strat.compute_loss(state, PRNGKey(7), tok.tokenize(clips).reshape(B, -1), aux=aux)
+        strat.compute_loss(state, PRNGKey(7), tok.tokenize(clips).reshape(B, -1), aux=aux, want_grads=False)
         return round(float(aux["per_example"].mean().item()) / D, 4)
     before = mse()
     for _ in range(steps):

@@ -220,14 +220,17 @@ int mfc_cnx_bwd_main(int dtype, int64_t R, int s, const void* h0, const float* s
  * halo, no repeated conv / LayerNorm).  Results equal the h1-based entry points up to the rounding of n1 to `dtype`
  * (bit-identical forward in fp32 storage; in bf16 the expansion consumed the same bf16 n1 anyway). */
 
-/* mfc_cnx_stats that also writes n1 [R,s,s,16] (dtype) and rho1 [R,s,s] (fp32) for the primal rows. */
+/* mfc_cnx_stats that also writes n1 [R,s,s,16] (dtype) and rho1 [R,s,s] (fp32) of the primal rows and, when h1dot
+ * and n1dot_out are given, the tangent of n1 [R,s,s,16] (dtype). */
 int mfc_cnx_stats_save(int dtype, int64_t R, int s, const void* h1, const void* h1dot,
                        const float* scale, const float* shift, const float* scaledot, const float* shiftdot,
                        const mfc_cnx_params* p, float* S1, float* S2, float* ws, void* n1_out, float* rho1_out,
-                       void* stream);
-/* mfc_cnx_apply (primal rows only) from n1; h1 is read for the residual branch o = ... + FiLM(h1). */
-int mfc_cnx_apply_n1(int dtype, int64_t R, int s, const void* n1, const void* h1, const float* scale,
-                     const float* shift, const mfc_cnx_params* p, const float* q, void* o, void* stream);
+                       void* n1dot_out, void* stream);
+/* mfc_cnx_apply from n1 (and, n1dot != NULL, the tangent from n1dot: then h1dot, scaledot, shiftdot, qdot, odot are
+ * required); h1 / h1dot are read for the residual branch o = ... + FiLM(h1).  Bit-identical to mfc_cnx_apply. */
+int mfc_cnx_apply_n1(int dtype, int64_t R, int s, const void* n1, const void* n1dot, const void* h1, const void* h1dot,
+                     const float* scale, const float* shift, const float* scaledot, const float* shiftdot,
+                     const mfc_cnx_params* p, const float* q, const float* qdot, void* o, void* odot, void* stream);
 /* mfc_cnx_bwd_stats / mfc_cnx_bwd_main from n1 (and rho1): same outputs, same workspace contract. */
 int mfc_cnx_bwd_stats_n1(int dtype, int64_t R, int s, const void* n1, const mfc_cnx_params* p, const float* q,
                          const void* dout, float* dq, float* ws, void* stream);

@@ -67,8 +67,8 @@ SIGNATURES = {
     "mfc_cnx_ws_elems": (c_int64, [c_int64, c_int]),
     "mfc_grn_bwd_finalize": (c_int, [c_int64, _P, _P, _P, _P, _P]),
     "mfc_cnx_bwd_main": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "mfc_cnx_stats_save": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "mfc_cnx_apply_n1": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_cnx_stats_save": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_cnx_apply_n1": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_cnx_bwd_stats_n1": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_cnx_bwd_main_n1": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_cnx_bwd_conv": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

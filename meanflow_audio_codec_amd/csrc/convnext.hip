@@ -690,6 +690,7 @@ struct FwdArgs {
     void* o; void* od;
     float* ws;   // stats mode: per-(workgroup, row) records of REC_STATS floats
     void* n1_out; float* rho1_out;   // stats mode, optional: n1 = LN(c1) [R, s, s, 16] (storage dtype) and its 1/sigma [R, s, s]
+    void* n1d_out;                   // ... and (tangent rows) the tangent of n1
 };
 
 template <typename T, bool JVP>
@@ -729,8 +730,8 @@ cnx_fwd_kernel(FwdArgs a) {
     constexpr bool K32 = JVP || MODE == 0;   // measured: -7 % on the JVP kernels, -3 % on the plain stats pass, 0 on plain apply
     RowW<T, JVP, K32> rw;
     // stores between a DMA request and its wait (statistics mode: the n1 / 1-sigma stores, out of bounds when not asked for)
-    constexpr int S_VMEM = MODE == 1 ? RPW * (JVP ? 2 : 1) : RPW * 2;
-    __amdgpu_buffer_rsrc_t rs_n1 = make_rsrc(nullptr, 0), rs_r1 = make_rsrc(nullptr, 0);
+    constexpr int S_VMEM = MODE == 1 ? RPW * (JVP ? 2 : 1) : RPW * (JVP ? 3 : 2);
+    __amdgpu_buffer_rsrc_t rs_n1 = make_rsrc(nullptr, 0), rs_r1 = make_rsrc(nullptr, 0), rs_n1d = make_rsrc(nullptr, 0);
 
     int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
     int64_t t1 = t0 + a.geo.chunk < a.geo.total ? t0 + a.geo.chunk : a.geo.total;
@@ -788,6 +789,8 @@ cnx_fwd_kernel(FwdArgs a) {
                 // (empty resources when the caller does not keep n1: every store is then dropped by the hardware)
                 rs_n1 = make_rsrc(a.n1_out ? (const T*)a.n1_out + r * img : nullptr, a.n1_out ? (uint32_t)(img * sizeof(T)) : 0u);
                 rs_r1 = make_rsrc(a.rho1_out ? a.rho1_out + r * (img / 16) : nullptr, a.rho1_out ? (uint32_t)(img / 16 * sizeof(float)) : 0u);
+                if constexpr (JVP)
+                    rs_n1d = make_rsrc(a.n1d_out ? (const T*)a.n1d_out + r * img : nullptr, a.n1d_out ? (uint32_t)(img * sizeof(T)) : 0u);
             }
             if constexpr (MODE == 1) {
 #pragma unroll
@@ -845,6 +848,7 @@ cnx_fwd_kernel(FwdArgs a) {
                 buf_st_frag(rs_n1, ok ? (uint32_t)((pix * 16 + 4 * q) * sizeof(T)) : BUF_OOB, f.n1f);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, f.rho1), rs_r1,
                                                       (ok && q == 0) ? pix * 4u : BUF_OOB, 0, 0);
+                if constexpr (JVP) buf_st_frag(rs_n1d, ok ? (uint32_t)((pix * 16 + 4 * q) * sizeof(T)) : BUF_OOB, f.n1df);
             } else {
                 f32x4 p1 = ld_f32x4(w.bp), p1d = z4;
 #pragma unroll
@@ -893,6 +897,7 @@ cnx_fwd_kernel(FwdArgs a) {
                 } else {
                     buf_st4(rs_n1, BUF_OOB, zv, (const T*)nullptr);
                     __builtin_amdgcn_raw_buffer_store_b32(0u, rs_r1, BUF_OOB, 0, 0);
+                    if constexpr (JVP) buf_st4(rs_n1d, BUF_OOB, zv, (const T*)nullptr);
                 }
             }
         }
@@ -1504,10 +1509,11 @@ inline Geo make_pix_geo(int64_t R, int s, int64_t maxBlocks, int64_t& grid) {
 struct PixArgs {
     Geo geo;
     const void* n1; const float* rho1; const void* h1; const void* dout;
-    const float* sc; const float* sh;
+    const void* n1d; const void* h1d;       // tangent rows (apply)
+    const float* sc; const float* sh; const float* scd; const float* shd;
     Dev p;
-    const float* q; const float* kG;
-    void* o; void* dc1;
+    const float* q; const float* qd; const float* kG;
+    void* o; void* od; void* dc1;
     float* ws;
 };
 
@@ -1523,9 +1529,11 @@ __device__ inline void expand_gelu(const FwdW<T>& w, const typename Frag<T>::typ
     }
 }
 
-// MODE 1 of cnx_fwd_kernel from n1: o = (Wp^T (gelu(We^T n1 + be) (gamma + q) + beta) + bp) * ls + (1 + scale) h1 + shift
-template <typename T>
-__global__ void __launch_bounds__(NT, sizeof(T) == 2 ? 4 : 1)
+// MODE 1 of cnx_fwd_kernel from n1: o = (Wp^T (gelu(We^T n1 + be) (gamma + q) + beta) + bp) * ls + (1 + scale) h1 + shift,
+// and (JVP) its tangent from the kept tangent of n1 -- the same expressions, in the same order, as the tile kernel
+// evaluates after its LayerNorm: results are bit-identical.
+template <typename T, bool JVP>
+__global__ void __launch_bounds__(NT, sizeof(T) == 2 ? (JVP ? 3 : 4) : 1)
 cnx_apply_n1_kernel(PixArgs a) {
     typedef typename Frag<T>::type frag_t;
     const int lane = threadIdx.x & 63;
@@ -1542,22 +1550,29 @@ cnx_apply_n1_kernel(PixArgs a) {
     int64_t j = t0 - r * spi;
     int64_t rcur = -1;
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 gq[2] = {z4, z4}, sc14 = z4, sh4 = z4;
-    __amdgpu_buffer_rsrc_t rs_o = make_rsrc(nullptr, 0);
+    f32x4 gq[2] = {z4, z4}, qdv[2] = {z4, z4}, sc14 = z4, sh4 = z4, scd4 = z4, shd4 = z4;
+    __amdgpu_buffer_rsrc_t rs_o = make_rsrc(nullptr, 0), rs_od = make_rsrc(nullptr, 0);
     auto off_of = [&](int64_t jj) -> uint32_t {
         const int64_t px = (jj * 4 + wave) * 16 + m;
         return px < npix ? (uint32_t)((px * 16 + 4 * q) * sizeof(T)) : BUF_OOB;
     };
-    auto fetch = [&](int64_t rr, int64_t jj, frag_t& n, frag_t& h) {
+    struct Ops { frag_t n, h, nd, hd; };
+    auto fetch = [&](int64_t rr, int64_t jj, Ops& o) {
         const uint32_t off = off_of(jj);
-        n = buf_ld_frag(make_rsrc((const T*)a.n1 + rr * img, (uint32_t)(img * sizeof(T))), off, (const T*)nullptr);
-        h = buf_ld_frag(make_rsrc((const T*)a.h1 + rr * img, (uint32_t)(img * sizeof(T))), off, (const T*)nullptr);
+        const uint32_t bytes = (uint32_t)(img * sizeof(T));
+        o.n = buf_ld_frag(make_rsrc((const T*)a.n1 + rr * img, bytes), off, (const T*)nullptr);
+        o.h = buf_ld_frag(make_rsrc((const T*)a.h1 + rr * img, bytes), off, (const T*)nullptr);
+        if constexpr (JVP) {
+            o.nd = buf_ld_frag(make_rsrc((const T*)a.n1d + rr * img, bytes), off, (const T*)nullptr);
+            o.hd = buf_ld_frag(make_rsrc((const T*)a.h1d + rr * img, bytes), off, (const T*)nullptr);
+        }
     };
-    frag_t nn, hn;
-    fetch(r, j, nn, hn);
+    Ops nx;
+    fetch(r, j, nx);
     for (int64_t t = t0; t < t1; ++t) {
-        const frag_t n1f = nn, h1f = hn;
-        land(n1f); land(h1f);
+        const Ops cur = nx;
+        land(cur.n); land(cur.h);
+        if constexpr (JVP) { land(cur.nd); land(cur.hd); }
         const int64_t rt = r, jt = j;
         if (++j == spi) { j = 0; ++r; }
         if (rt != rcur) {
@@ -1565,39 +1580,77 @@ cnx_apply_n1_kernel(PixArgs a) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) gq[jj][i] = a.q[rt * 32 + 16 * jj + 4 * q + i] + w.gam[jj][i];
+                for (int i = 0; i < 4; ++i) {
+                    gq[jj][i] = a.q[rt * 32 + 16 * jj + 4 * q + i];
+                    if constexpr (JVP) qdv[jj][i] = a.qd[rt * 32 + 16 * jj + 4 * q + i];
+                }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 sc14[i] = 1.0f + a.sc[rt * 16 + 4 * q + i];
                 sh4[i] = a.sh[rt * 16 + 4 * q + i];
+                if constexpr (JVP) { scd4[i] = a.scd[rt * 16 + 4 * q + i]; shd4[i] = a.shd[rt * 16 + 4 * q + i]; }
             }
             land(gq[0]); land(gq[1]); land(sc14); land(sh4);
+            if constexpr (JVP) { land(qdv[0]); land(qdv[1]); land(scd4); land(shd4); }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) gq[jj] = gq[jj] + ld_f32x4(w.gam[jj]);
             rs_o = make_rsrc((const T*)a.o + rt * img, (uint32_t)(img * sizeof(T)));
+            if constexpr (JVP) rs_od = make_rsrc((const T*)a.od + rt * img, (uint32_t)(img * sizeof(T)));
         }
         __builtin_amdgcn_sched_barrier(0);
         // next step's operands (past the end: this step again -- the instruction count stays fixed)
-        if (t + 1 < t1) fetch(r, j, nn, hn); else fetch(rt, jt, nn, hn);
+        if (t + 1 < t1) fetch(r, j, nx); else fetch(rt, jt, nx);
         __builtin_amdgcn_sched_barrier(0);
-        f32x4 g[2], gp[2];
-        expand_gelu<T, false>(w, n1f, g, gp);
-        f32x4 p1 = ld_f32x4(w.bp);
+        f32x4 g[2], gp[2], gd[2];
+        expand_gelu<T, JVP>(w, cur.n, g, gp);
+        if constexpr (JVP) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                f32x4 ed = z4;
+                mma16(ed, w.we[jj], cur.nd);
+                gd[jj] = ed * gp[jj];
+            }
+        }
+        f32x4 p1 = ld_f32x4(w.bp), p1d = z4;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             frag_t yf;
             const f32x4 yv = fma4(g[jj], gq[jj], ld_f32x4(w.bet[jj]));
             make_frag(yf, yv[0], yv[1], yv[2], yv[3]);
             mma16(p1, w.wp[jj], yf);
+            if constexpr (JVP) {
+                frag_t ydf;
+                const f32x4 ydv = fma4(gd[jj], gq[jj], g[jj] * qdv[jj]);
+                make_frag(ydf, ydv[0], ydv[1], ydv[2], ydv[3]);
+                mma16(p1d, w.wp[jj], ydf);
+            }
         }
         float hv[4], ov[4];
-        unfrag(h1f, hv);
-        const f32x4 o4 = fma4(p1, ld_f32x4(w.ls), fma4(sc14, ld_f32x4(hv), sh4));
+        unfrag(cur.h, hv);
+        const f32x4 nv = ld_f32x4(hv), ls4 = ld_f32x4(w.ls);
+        const f32x4 o4 = fma4(p1, ls4, fma4(sc14, nv, sh4));
 #pragma unroll
         for (int i = 0; i < 4; ++i) ov[i] = o4[i];
-        buf_st4(rs_o, off_of(jt), ov, (const T*)nullptr);
+        const uint32_t goff = off_of(jt);
+        buf_st4(rs_o, goff, ov, (const T*)nullptr);
+        if constexpr (JVP) {
+            float hdv[4];
+            unfrag(cur.hd, hdv);
+            const f32x4 od4 = fma4(p1d, ls4, fma4(sc14, ld_f32x4(hdv), fma4(scd4, nv, shd4)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ov[i] = od4[i];
+            buf_st4(rs_od, goff, ov, (const T*)nullptr);
+        }
     }
 }
 
-// MODE 0 / MODE 1 of cnx_bwd_kernel from n1 (and, MODE 1, its 1/sigma rho1)
+// MODE 0 / MODE 1 of cnx_bwd_kernel from n1 (and, MODE 1, its 1/sigma rho1).
+// Per-pixel arithmetic is kept in accumulator quads (packed f32 VALU) and the layer scale is folded out of the loop:
+//   dy = Wp (ls * dout)      ->  A operand Wp * diag(ls), B operand the dout fragment as loaded (no per-pixel product);
+//   d con_w[e][c] = ls[c] * sum_p y[p][e] dout[p][c]   ->  the pixel contraction takes the raw dout tile, ls at the flush;
+//   d ls[c] = sum_p dout[p][c] p1[p][c], p1 = bp + Wp^T y   ->  bp[c] * sum_p dout[p][c] + sum_e Wp[e][c] M[e][c] with the
+//   same M = sum_p y[p][e] dout[p][c] -- the per-pixel contraction p1 disappears; sum_p dout is one more MFMA on the
+//   transposed dout tile (a row of ones as the other operand).
 template <typename T, int MODE>
 __global__ void __launch_bounds__(NT, sizeof(T) == 2 ? (MODE == 0 ? 4 : 3) : 1)
 cnx_bwd_n1_kernel(PixArgs a) {
@@ -1611,11 +1664,19 @@ cnx_bwd_n1_kernel(PixArgs a) {
     float* red = reinterpret_cast<float*>(smem + (((size_t)NWAVES * WS_TILES * 16 * CS * sizeof(T)) + 15) / 16 * 16);
     FwdW<T> w;
     w.load(a.p, q, m);
-    const T* pw = (const T*)a.p.con_w;  // [32][16]: dy[e] = sum_c Wp[e][c] dp1[c]
-    frag_t wpT[2] = {load_bfrag<T>(pw, 1, 16, 0, 0, q, m), load_bfrag<T>(pw, 1, 16, 0, 16, q, m)};
+    const T* pw = (const T*)a.p.con_w;  // [32][16]: dy[e] = sum_c Wp[e][c] ls[c] dout[c]
+    frag_t wpT[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        float wv[4];
+        unfrag(load_bfrag<T>(pw, 1, 16, 0, 16 * jj, q, m), wv);       // lane (q, m): Wp[e = 16 jj + m][c = 4q + i]
+        make_frag(wpT[jj], wv[0] * w.ls[0], wv[1] * w.ls[1], wv[2] * w.ls[2], wv[3] * w.ls[3]);
+    }
     const T* ew = (const T*)a.p.exp_w;  // [16][32]: dn1[c] = sum_e We[c][e] de[e]
     frag_t weT[2] = {load_bfrag<T>(ew, 1, 32, 0, 0, q, m), load_bfrag<T>(ew, 1, 32, 16, 0, q, m)};
     land(wpT[0]); land(wpT[1]); land(weT[0]); land(weT[1]);
+    frag_t ones;
+    make_frag(ones, 1.0f, 1.0f, 1.0f, 1.0f);
     const int s = a.geo.s;
     const int64_t npix = (int64_t)s * s, img = npix * 16, spi = a.geo.tilesPerImg;
     const int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
@@ -1623,11 +1684,12 @@ cnx_bwd_n1_kernel(PixArgs a) {
     int64_t r = t0 < t1 ? t0 / spi : 0;
     int64_t j = t0 < t1 ? t0 - r * spi : 0;
     int64_t rcur = -1;
-    float gq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, kg[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    float dqp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    f32x4 aWp[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, aWe[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-    float dls[4] = {0.f, 0.f, 0.f, 0.f};
-    float dbe[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 gq[2] = {z4, z4}, kg[2] = {z4, z4};
+    f32x4 dqp[2] = {z4, z4};
+    f32x4 aWp[2] = {z4, z4}, aWe[2] = {z4, z4}, aS = z4;   // aS[e][c] = sum_p dout[p][c] on every row e
+    f32x4 dbe[2] = {z4, z4};
+    const f32x4 bet4[2] = {ld_f32x4(w.bet[0]), ld_f32x4(w.bet[1])};
     __amdgpu_buffer_rsrc_t rs_dc = make_rsrc(nullptr, 0);
     int krow = 0;
     auto flush_row = [&]() {
@@ -1670,7 +1732,7 @@ cnx_bwd_n1_kernel(PixArgs a) {
     float rn = 0.f;
     if (t0 < t1) fetch(r, j, nn, dn, rn);
     for (int64_t t = t0; t < t1; ++t) {
-        const frag_t n1f = nn, dof = dn;
+        const frag_t n1f = nn, dof = dn;                    // dout: zero outside the image
         const float rho1 = rn;
         land(n1f); land(dof);
         if constexpr (MODE == 1) land(rho1);
@@ -1686,86 +1748,68 @@ cnx_bwd_n1_kernel(PixArgs a) {
                     gq[jj][i] = a.q[rt * 32 + 16 * jj + 4 * q + i] + w.gam[jj][i];
                     if constexpr (MODE == 1) kg[jj][i] = a.kG[rt * 32 + 16 * jj + 4 * q + i];
                 }
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { land(gq[jj][i]); if constexpr (MODE == 1) land(kg[jj][i]); }
+            land(gq[0]); land(gq[1]);
+            if constexpr (MODE == 1) { land(kg[0]); land(kg[1]); }
             if constexpr (MODE == 1) rs_dc = make_rsrc((const T*)a.dc1 + rt * img, (uint32_t)(img * sizeof(T)));
         }
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < t1) fetch(r, j, nn, dn, rn); else fetch(rt, jt, nn, dn, rn);
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t goff = off_of(jt);
-        const bool ok = goff != BUF_OOB;
-        float dov[4];
-        unfrag(dof, dov);                                   // zero outside the image
         f32x4 g[2], gp[2];
         expand_gelu<T, MODE == 1>(w, n1f, g, gp);
-        float dp1[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dp1[i] = dov[i] * w.ls[i];
-        frag_t dp1f;
-        make_frag(dp1f, dp1[0], dp1[1], dp1[2], dp1[3]);
         f32x4 dy[2];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-            dy[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-            mma16(dy[jj], wpT[jj], dp1f);      // dy^T = Wp dp1^T
+            dy[jj] = z4;
+            mma16(dy[jj], wpT[jj], dof);       // dy^T = (Wp diag(ls)) dout^T
         }
         if constexpr (MODE == 0) {
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dqp[jj][i] += dy[jj][i] * g[jj][i];
+            for (int jj = 0; jj < 2; ++jj) dqp[jj] = fma4(dy[jj], g[jj], dqp[jj]);
         } else {
-            float n1[4];
-            unfrag(n1f, n1);
-            float yv[2][4];
-            f32x4 p1 = f32x4{w.bp[0], w.bp[1], w.bp[2], w.bp[3]};
-            frag_t yf[2];
+            // the pixels past the end of the image (last step of an image only) must not reach d exp_b: g != 0 there
+            f32x4 kge[2] = {kg[0], kg[1]};
+            if (jt == spi - 1 && goff == BUF_OOB) { kge[0] = z4; kge[1] = z4; }
+            frag_t yf[2], def[2];
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) yv[jj][i] = g[jj][i] * gq[jj][i] + w.bet[jj][i];
-                make_frag(yf[jj], yv[jj][0], yv[jj][1], yv[jj][2], yv[jj][3]);
-            }
-            mma_pair(p1, w.wp[0], w.wp[1], yf[0], yf[1]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dls[i] += dov[i] * p1[i];
-            frag_t def[2];
-            f32x4 dn1 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                float de[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float dg = dy[jj][i] * gq[jj][i] + g[jj][i] * kg[jj][i];
-                    de[i] = ok ? dg * gp[jj][i] : 0.f;
-                    dbe[jj][i] += de[i];
-                }
+                const f32x4 yv = fma4(g[jj], gq[jj], bet4[jj]);
+                make_frag(yf[jj], yv[0], yv[1], yv[2], yv[3]);
+                const f32x4 de = fma4(dy[jj], gq[jj], g[jj] * kge[jj]) * gp[jj];
+                dbe[jj] = dbe[jj] + de;
                 make_frag(def[jj], de[0], de[1], de[2], de[3]);
             }
+            f32x4 dn1 = z4;
             mma_pair(dn1, weT[0], weT[1], def[0], def[1]);      // dn1^T = We de^T
-            float dnv[4] = {dn1[0], dn1[1], dn1[2], dn1[3]}, dc[4];
-            ln_bwd_a(dnv, n1, rho1, dc);
+            // LayerNorm backward: dc = rho (dn - mean(dn) - n mean(dn n))
+            float n1[4];
+            unfrag(n1f, n1);
+            const f32x4 n4 = ld_f32x4(n1);
+            float m1 = (dn1[0] + dn1[1]) + (dn1[2] + dn1[3]);
+            float m2 = dn1[0] * n1[0] + dn1[1] * n1[1] + dn1[2] * n1[2] + dn1[3] * n1[3];
+            red_q2(m1, m2);
+            const f32x4 dc4 = (fma4(n4, splat4(m2 * (-1.0f / 16.0f)), dn1) - splat4(m1 * (1.0f / 16.0f))) * splat4(rho1);
+            float dc[4] = {dc4[0], dc4[1], dc4[2], dc4[3]};
             buf_st4(rs_dc, goff, dc, (const T*)nullptr);
             // weight gradients contract over the 16 pixels of the wave row: one batched transpose through the wave scratch
             *reinterpret_cast<frag_t*>(wsT + (0 * 16 + m) * CS + 4 * q) = yf[0];
             *reinterpret_cast<frag_t*>(wsT + (1 * 16 + m) * CS + 4 * q) = yf[1];
-            *reinterpret_cast<frag_t*>(wsT + (2 * 16 + m) * CS + 4 * q) = dp1f;
+            *reinterpret_cast<frag_t*>(wsT + (2 * 16 + m) * CS + 4 * q) = dof;
             *reinterpret_cast<frag_t*>(wsT + (3 * 16 + m) * CS + 4 * q) = n1f;     // (rows outside the image meet de = 0)
             *reinterpret_cast<frag_t*>(wsT + (4 * 16 + m) * CS + 4 * q) = def[0];
             *reinterpret_cast<frag_t*>(wsT + (5 * 16 + m) * CS + 4 * q) = def[1];
             lds_fence();
-            const frag_t tdp = pix_k_frag<T>(wsT + 2 * 16 * CS, q, m);
+            const frag_t tdo = pix_k_frag<T>(wsT + 2 * 16 * CS, q, m);
             const frag_t tn1 = pix_k_frag<T>(wsT + 3 * 16 * CS, q, m);
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const frag_t ty = pix_k_frag<T>(wsT + jj * 16 * CS, q, m);
                 const frag_t tde = pix_k_frag<T>(wsT + (4 + jj) * 16 * CS, q, m);
-                mma16(aWp[jj], ty, tdp);    // [e][c] += y^T dp1
+                mma16(aWp[jj], ty, tdo);    // M[e][c] += y^T dout
                 mma16(aWe[jj], tn1, tde);   // [c][e] += n1^T de
             }
+            mma16(aS, ones, tdo);           // every row: sum_p dout[p][c]
             lds_fence();
         }
     }
@@ -1778,13 +1822,20 @@ cnx_bwd_n1_kernel(PixArgs a) {
     }
     if constexpr (MODE == 1) {
         float* scratch = red;   // con_w [32][16] | exp_w [16][32] | ls [16] | exp_b [32]
-        float vls[4], vbe[2][4];
+        // this lane's share of d ls[c = m]: bp[c] sum_p dout[p][c] (once: the lanes q = 0) + sum over its 8 rows e of
+        // Wp[e][c] M[e][c]; then the four q-lanes of a column are added
+        const float lsm = a.p.ls[m];
+        float dlsv = q == 0 ? a.p.con_b[m] * aS[0] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            vls[i] = red_m(dls[i]);
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dlsv += St<T>::ld(pw + (16 * jj + 4 * q + e) * 16 + m) * aWp[jj][e];
+        dlsv = red_q(dlsv);
+        float vbe[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) vbe[jj][i] = red_m(dbe[jj][i]);
-        }
         __syncthreads();
         for (int i = threadIdx.x; i < REC_MAIN; i += NT) scratch[i] = 0.f;
         __syncthreads();
@@ -1794,16 +1845,15 @@ cnx_bwd_n1_kernel(PixArgs a) {
                 for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        scratch[(16 * jj + 4 * q + e) * 16 + m] += aWp[jj][e];
+                        scratch[(16 * jj + 4 * q + e) * 16 + m] += aWp[jj][e] * lsm;
                         scratch[512 + (4 * q + e) * 32 + 16 * jj + m] += aWe[jj][e];
                     }
+                if (q == 0) scratch[1024 + m] += dlsv;
                 if (m == 0) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        scratch[1024 + 4 * q + i] += vls[i];
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int jj = 0; jj < 2; ++jj) scratch[1040 + 16 * jj + 4 * q + i] += vbe[jj][i];
-                    }
                 }
             }
             __syncthreads();
@@ -1984,8 +2034,8 @@ inline bool params_ok(const mfc_cnx_params* p) {
 // (-8 %), the 2-per-CU kernels exactly one round (-3..-7 %); the conv-gradient kernel, three per CU since its dout
 // tile became compact and single-buffered, one round of 768 (-7 % against two per CU).  MFC_CNX_MAX_BLOCKS / mfc_cnx_max_blocks override all.
 enum CnxKind { K_STATS = 0, K_APPLY, K_STATS_JVP, K_APPLY_JVP, K_BWD_STATS, K_BWD_MAIN, K_BWD_CONV, K_APPLY_N1, K_BWD_STATS_N1,
-               K_BWD_MAIN_N1, K_NKIND };
-static const int64_t DEFAULT_BLOCKS[K_NKIND] = {3072, 3072, 2304, 512, 3072, 512, 768, 3072, 3072, 2304};
+               K_BWD_MAIN_N1, K_APPLY_JVP_N1, K_NKIND };
+static const int64_t DEFAULT_BLOCKS[K_NKIND] = {3072, 3072, 2304, 512, 3072, 512, 768, 3072, 3072, 2304, 2304};
 inline bool kind_is_pix(int k) { return k >= K_APPLY_N1; }
 static int64_t MAX_BLOCKS = getenv("MFC_CNX_MAX_BLOCKS") ? atoll(getenv("MFC_CNX_MAX_BLOCKS")) : 0;   // 0: per-kernel defaults
 inline int64_t max_blocks(CnxKind k) { return MAX_BLOCKS > 0 ? MAX_BLOCKS : DEFAULT_BLOCKS[k]; }
@@ -2027,7 +2077,8 @@ int fwd_launch(bool jvp, int mode, const FwdArgs& a, int64_t grid, hipStream_t s
 int fwd_common(int dtype, int mode, int64_t R, int s, const void* h0, const void* h0dot,
                const float* scale, const float* shift, const float* scaledot, const float* shiftdot,
                const mfc_cnx_params* p, float* S1, float* S2, const float* q, const float* qdot,
-               void* o, void* odot, float* ws, void* stream, void* n1_out = nullptr, float* rho1_out = nullptr) {
+               void* o, void* odot, float* ws, void* stream, void* n1_out = nullptr, float* rho1_out = nullptr,
+               void* n1dot_out = nullptr) {
     if (!h0 || !scale || !shift || !params_ok(p)) return MFC_EFAULT;
     if (R <= 0 || s <= 0) return MFC_EINVAL;
     if (s > MAX_S) return MFC_ENOSYS;
@@ -2041,7 +2092,7 @@ int fwd_common(int dtype, int mode, int64_t R, int s, const void* h0, const void
     a.geo = make_geo(R, s, max_blocks(mode == 0 ? (jvp ? K_STATS_JVP : K_STATS) : (jvp ? K_APPLY_JVP : K_APPLY)), grid);
     a.h0 = h0; a.h0d = h0dot; a.sc = scale; a.sh = shift; a.scd = scaledot; a.shd = shiftdot;
     a.p = to_dev(p); a.S1 = S1; a.S2 = S2; a.q = q; a.qd = qdot; a.o = o; a.od = odot; a.ws = ws;
-    a.n1_out = n1_out; a.rho1_out = rho1_out;
+    a.n1_out = n1_out; a.rho1_out = rho1_out; a.n1d_out = n1dot_out;
     hipStream_t st = (hipStream_t)stream;
     int rc = dtype == MFC_F32 ? fwd_launch<float>(jvp, mode, a, grid, st) : fwd_launch<u16>(jvp, mode, a, grid, st);
     if (!rc && mode == 0) rc = reduce_rows(ws, a.geo, REC_STATS, 0, jvp ? 64 : 32, 32, S1, S2, st);
@@ -2061,10 +2112,11 @@ extern "C" int mfc_cnx_stats(int dtype, int64_t R, int s, const void* h1, const 
 extern "C" int mfc_cnx_stats_save(int dtype, int64_t R, int s, const void* h1, const void* h1dot,
                                   const float* scale, const float* shift, const float* scaledot,
                                   const float* shiftdot, const mfc_cnx_params* p, float* S1, float* S2,
-                                  float* ws, void* n1_out, float* rho1_out, void* stream) {
+                                  float* ws, void* n1_out, float* rho1_out, void* n1dot_out, void* stream) {
     if (!n1_out || !rho1_out) return MFC_EFAULT;
+    if (n1dot_out && !h1dot) return MFC_EINVAL;
     return fwd_common(dtype, 0, R, s, h1, h1dot, scale, shift, scaledot, shiftdot, p, S1, S2, nullptr, nullptr,
-                      nullptr, nullptr, ws, stream, n1_out, rho1_out);
+                      nullptr, nullptr, ws, stream, n1_out, rho1_out, n1dot_out);
 }
 
 namespace {
@@ -2075,16 +2127,25 @@ inline int pix_common(int dtype, int64_t R, int s) {
 }
 }  // namespace
 
-extern "C" int mfc_cnx_apply_n1(int dtype, int64_t R, int s, const void* n1, const void* h1, const float* scale,
-                                const float* shift, const mfc_cnx_params* p, const float* q, void* o, void* stream) {
+extern "C" int mfc_cnx_apply_n1(int dtype, int64_t R, int s, const void* n1, const void* n1dot, const void* h1,
+                                const void* h1dot, const float* scale, const float* shift, const float* scaledot,
+                                const float* shiftdot, const mfc_cnx_params* p, const float* q, const float* qdot, void* o,
+                                void* odot, void* stream) {
     if (!n1 || !h1 || !scale || !shift || !params_ok(p) || !q || !o) return MFC_EFAULT;
+    const bool jvp = n1dot != nullptr;
+    if (jvp && (!h1dot || !scaledot || !shiftdot || !qdot || !odot)) return MFC_EFAULT;
     if (int rc = pix_common(dtype, R, s)) return rc;
     PixArgs a = {};
     int64_t grid;
-    a.geo = make_pix_geo(R, s, max_blocks(K_APPLY_N1), grid);
-    a.n1 = n1; a.h1 = h1; a.sc = scale; a.sh = shift; a.p = to_dev(p); a.q = q; a.o = o;
+    a.geo = make_pix_geo(R, s, max_blocks(jvp ? K_APPLY_JVP_N1 : K_APPLY_N1), grid);
+    a.n1 = n1; a.n1d = n1dot; a.h1 = h1; a.h1d = h1dot; a.sc = scale; a.sh = shift; a.scd = scaledot; a.shd = shiftdot;
+    a.p = to_dev(p); a.q = q; a.qd = qdot; a.o = o; a.od = odot;
     hipStream_t st = (hipStream_t)stream;
-    return dtype == MFC_F32 ? launch_k(cnx_apply_n1_kernel<float>, grid, 0, st, a) : launch_k(cnx_apply_n1_kernel<u16>, grid, 0, st, a);
+    if (jvp)
+        return dtype == MFC_F32 ? launch_k(cnx_apply_n1_kernel<float, true>, grid, 0, st, a)
+                                : launch_k(cnx_apply_n1_kernel<u16, true>, grid, 0, st, a);
+    return dtype == MFC_F32 ? launch_k(cnx_apply_n1_kernel<float, false>, grid, 0, st, a)
+                            : launch_k(cnx_apply_n1_kernel<u16, false>, grid, 0, st, a);
 }
 
 extern "C" int mfc_cnx_bwd_stats_n1(int dtype, int64_t R, int s, const void* n1, const mfc_cnx_params* p, const float* q,

@@ -239,14 +239,15 @@ class ConditionalConvFlow:
             if keep_n1:
                 N1 = ctx.N1[i * R:(i + 1) * R] if save else N1s
                 r1 = (ctx.rho1[i] if save else rho1s).view(R, -1)
-                keep = lambda a, b: (N1[a:b], r1[a:b])
+                N1d = self._buf(("N1dot", n_tan), (n_tan, S), T, dev) if n_tan else None     # tangent of n1: scratch
+                keep = lambda a, b: (N1[a:b], r1[a:b]) if a else (N1[a:b], r1[a:b], N1d)
             else:
                 keep = lambda a, b: None
             if n_tan:
                 scd, shd = cp[R:, :16].contiguous(), cp[R:, 16:].contiguous()
                 _, _, G, q = ops.cnx_forward(H0[:n_tan], sc[:n_tan], sh[:n_tan], cw, s, h0dot=H0[R:],
                                              scaledot=scd, shiftdot=shd, out=O[:n_tan], outdot=O[R:],
-                                             use_grn=self.use_grn, keep=keep(0, n_tan) if save else None)
+                                             use_grn=self.use_grn, keep=keep(0, n_tan))
                 Gs.append(G); qs.append(q)
             if R > n_tan:
                 _, _, G, q = ops.cnx_forward(H0[n_tan:R], sc[n_tan:], sh[n_tan:], cw, s, out=O[n_tan:R],

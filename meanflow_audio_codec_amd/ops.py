@@ -159,9 +159,10 @@ def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, sh
     tangent of that LayerNorm (see ln16 / ln16_jvp, or the MFC_GEMM_LN16 / LN16T epilogue);
     returns (o, odot, G, q).  Runs mfc_cnx_stats -> mfc_grn_finalize -> mfc_cnx_apply.
 
-    ``keep = (n1, rho1)`` (buffers [R, s, s, 16] in h0's dtype and fp32 [R, s, s]): the statistics pass writes
-    n1 = LN(conv(FiLM(h1))) and its 1/sigma there (``mfc_cnx_stats_save``); a primal-only call then applies from n1
-    (``mfc_cnx_apply_n1``: no second conv / LayerNorm), and ``cnx_backward(.., n1=, rho1=)`` can start from them too."""
+    ``keep = (n1, rho1[, n1dot])`` (buffers [R, s, s, 16] in h0's dtype and fp32 [R, s, s]): the statistics pass writes
+    n1 = LN(conv(FiLM(h1))), its 1/sigma and (tangent rows) the tangent of n1 there (``mfc_cnx_stats_save``); the apply
+    pass then starts from them (``mfc_cnx_apply_n1``: no second conv / LayerNorm, bit-identical results), and
+    ``cnx_backward(.., n1=, rho1=)`` can too."""
     _lib.require_cuda(h0)
     R = h0.shape[0]
     dt = _lib.dtype_code(h0.dtype)
@@ -183,14 +184,20 @@ def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, sh
     qd = torch.empty_like(G) if jvp else None
     if keep is not None and not use_grn:
         raise _lib.MfcError("keep=(n1, rho1) needs the statistics pass (use_grn=True)")
+    n1d = None
     if keep is not None:
-        n1, rho1 = keep
+        n1, rho1 = keep[0], keep[1]
+        n1d = keep[2] if len(keep) > 2 else None         # scratch for the tangent of n1 (tangent rows)
         assert n1.shape == h0.shape and n1.dtype == h0.dtype and n1.is_contiguous()
         assert rho1.dtype == torch.float32 and rho1.is_contiguous() and rho1.numel() == R * s * s
+        if jvp and n1d is None:
+            n1d = torch.empty_like(h0)
+        if jvp:
+            assert n1d.shape == h0.shape and n1d.dtype == h0.dtype and n1d.is_contiguous()
         _lib.check(L.mfc_cnx_stats_save(dt, R, s, h0.data_ptr(), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
                                         _lib.ptr(scaledot), _lib.ptr(shiftdot), ctypes.byref(ps), S[0].data_ptr(),
-                                        S[1].data_ptr() if jvp else None, ws.data_ptr(), n1.data_ptr(), rho1.data_ptr(), st),
-                   "mfc_cnx_stats_save")
+                                        S[1].data_ptr() if jvp else None, ws.data_ptr(), n1.data_ptr(), rho1.data_ptr(),
+                                        n1d.data_ptr() if jvp else None, st), "mfc_cnx_stats_save")
     elif use_grn:
         _lib.check(L.mfc_cnx_stats(dt, R, s, h0.data_ptr(), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
                                    _lib.ptr(scaledot), _lib.ptr(shiftdot), ctypes.byref(ps), S[0].data_ptr(),
@@ -206,9 +213,11 @@ def cnx_forward(h0, scale, shift, w: dict, s: int, h0dot=None, scaledot=None, sh
             qd.zero_()
     o = out if out is not None else torch.empty_like(h0)
     od = (outdot if outdot is not None else torch.empty_like(h0)) if jvp else None
-    if keep is not None and not jvp:
-        _lib.check(L.mfc_cnx_apply_n1(dt, R, s, keep[0].data_ptr(), h0.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                      ctypes.byref(ps), q.data_ptr(), o.data_ptr(), st), "mfc_cnx_apply_n1")
+    if keep is not None:
+        _lib.check(L.mfc_cnx_apply_n1(dt, R, s, keep[0].data_ptr(), n1d.data_ptr() if jvp else None, h0.data_ptr(),
+                                      _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(), _lib.ptr(scaledot),
+                                      _lib.ptr(shiftdot), ctypes.byref(ps), q.data_ptr(), _lib.ptr(qd), o.data_ptr(),
+                                      _lib.ptr(od), st), "mfc_cnx_apply_n1")
         return o, od, G, q
     _lib.check(L.mfc_cnx_apply(dt, R, s, h0.data_ptr(), _lib.ptr(h0dot), scale.data_ptr(), shift.data_ptr(),
                                _lib.ptr(scaledot), _lib.ptr(shiftdot), ctypes.byref(ps), q.data_ptr(),

@@ -106,7 +106,7 @@ class _TwoTimeLoss(LossStrategy):
     kind = 0
 
     def _run(self, state, key, x, e, t, r, row0, global_batch, aux, *, nmin, nmax, mode, p, c, use_v_pass,
-             on_block=None, fused=None, row_stride=1):
+             on_block=None, fused=None, row_stride=1, want_grads=True):
         model, w = state.model, state.work
         x = _prep_x(x)
         B = x.shape[0]
@@ -158,10 +158,12 @@ class _TwoTimeLoss(LossStrategy):
         u, dudt, ctx = model.forward(w, z, cond_u, xdot=zdot, cond_dot=cdot, latents=latents, save=True,
                                      ctx=ctx_holder)
         loss, du, pe = ops.flow_loss(u, target, dudt=dudt, n_tan=n_tan, t=t, r=r, kind=self.kind, mode=mode, p=p,
-                                     c=c, Bglobal=Bg)
-        grads = state.grad_buffers()
-        _, dcond, dlat = model.backward(w, ctx, du, grads, on_block=on_block, fused=fused)
-        model.backward_conditioning(w, ctx, dcond, latents, grads, dlat=dlat)
+                                     c=c, Bglobal=Bg, want_grad=want_grads)
+        grads = None
+        if want_grads:          # (False: evaluation only -- loss and ``aux``, no reverse pass, no gradient buffers)
+            grads = state.grad_buffers()
+            _, dcond, dlat = model.backward(w, ctx, du, grads, on_block=on_block, fused=fused)
+            model.backward_conditioning(w, ctx, dcond, latents, grads, dlat=dlat)
         if aux is not None:
             inv = None if perm is None else torch.argsort(perm)
             un = (lambda a: a) if inv is None else (lambda a: a[inv])
@@ -182,10 +184,10 @@ class MeanFlowLoss(_TwoTimeLoss):
         self.c = c
 
     def compute_loss(self, state, key, x, *, e=None, t=None, r=None, row0=0, global_batch=None, aux=None,
-                     on_block=None, fused=None, row_stride=1):
+                     on_block=None, fused=None, row_stride=1, want_grads=True):
         return self._run(state, key, x, e, t, r, row0, global_batch, aux, nmin=0.0, nmax=1.0, mode=2,
                          p=1.0 - self.gamma, c=self.c, use_v_pass=False, on_block=on_block, fused=fused,
-                         row_stride=row_stride)
+                         row_stride=row_stride, want_grads=want_grads)
 
 
 class ImprovedMeanFlowLoss(_TwoTimeLoss):
@@ -199,8 +201,8 @@ class ImprovedMeanFlowLoss(_TwoTimeLoss):
         self.use_weighted_loss = use_weighted_loss
 
     def compute_loss(self, state, key, x, *, e=None, t=None, r=None, row0=0, global_batch=None, aux=None,
-                     on_block=None, fused=None, row_stride=1):
+                     on_block=None, fused=None, row_stride=1, want_grads=True):
         ns = self.noise_schedule
         return self._run(state, key, x, e, t, r, row0, global_batch, aux, nmin=ns.noise_min, nmax=ns.noise_max,
                          mode=_loss_mode(self.use_weighted_loss), p=1.0, c=1e-3, use_v_pass=True, on_block=on_block,
-                         fused=fused, row_stride=row_stride)
+                         fused=fused, row_stride=row_stride, want_grads=want_grads)

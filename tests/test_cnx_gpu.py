@@ -151,8 +151,13 @@ def test_kept_n1_paths(dtype, tol, btol, R, s):
     h0d = torch.randn(h0.shape, generator=g, dtype=torch.float64)
     h1d = ops.ln16_jvp(h1, rho, h0d.to(dtype).cuda())
     n1b, rho1b = torch.zeros_like(n1), torch.zeros_like(rho1)
-    ops.cnx_forward(h1, f32(sc), f32(sh), w, s, h0dot=h1d, scaledot=f32(0.1 * sc), shiftdot=f32(0.1 * sh), keep=(n1b, rho1b))
+    jkw = dict(h0dot=h1d, scaledot=f32(0.1 * sc), shiftdot=f32(0.1 * sh))
+    oj, odj, Gj, qj = ops.cnx_forward(h1, f32(sc), f32(sh), w, s, keep=(n1b, rho1b), **jkw)
     assert torch.equal(n1b, n1) and torch.equal(rho1b, rho1)
+    # ... and the tangent of n1: the tangent apply pass from (n1, n1dot) is bit-identical to the tile kernel as well
+    oj_old, odj_old, Gj_old, qj_old = ops.cnx_forward(h1, f32(sc), f32(sh), w, s, **jkw)
+    assert torch.equal(Gj, Gj_old) and torch.equal(qj, qj_old) and torch.equal(oj, oj_old)
+    assert torch.equal(odj, odj_old), (odj.float() - odj_old.float()).abs().max().item()
     # reverse pass from n1
     gacc = {k: torch.zeros(v.shape, dtype=torch.float32, device="cuda") for k, v in w.items()}
     dh0, dsc, dsh = ops.cnx_backward(h1, f32(sc), f32(sh), w, s, G, q, dout.to(dtype).cuda(), gacc, rho0=rho, n1=n1, rho1=rho1)
