@@ -8,6 +8,7 @@
 // (MLP flow: mod_div = 1, views into the conditioning MLP's output) and per-sample modulation
 // broadcast over tokens (Mixer: mod_div = tokens per sample) share the kernels.
 #include "mfc_common.h"
+#include <initializer_list>
 
 namespace {
 
@@ -147,6 +148,161 @@ __global__ void __launch_bounds__(AT) adaln_bwd_mod_kernel(AdaArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Narrow rows (the Mixer: W = 16 channels per token, 10^5 rows): a whole workgroup per 64-byte row leaves 255 of 256
+// lanes idle.  Here a row is held by LPR = W * sizeof(T) / 16 lanes (one 16-byte piece each), a wave covers
+// 64 / LPR rows per step (fully coalesced), and the row reductions are LPR-lane butterflies.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T> struct Piece;
+template <> struct Piece<float> { static constexpr int VW = 4; typedef f32x4 vec; };
+template <> struct Piece<u16> { static constexpr int VW = 8; typedef s16x8 vec; };
+template <typename T> __device__ inline void ld_piece(const T* p, float v[Piece<T>::VW]) {
+    typename Piece<T>::vec t = *reinterpret_cast<const typename Piece<T>::vec*>(p);
+#pragma unroll
+    for (int i = 0; i < Piece<T>::VW; ++i) { T e = (T)t[i]; v[i] = St<T>::ld(&e); }
+}
+template <typename T> __device__ inline void st_piece(T* p, const float v[Piece<T>::VW]) {
+    typename Piece<T>::vec t;
+#pragma unroll
+    for (int i = 0; i < Piece<T>::VW; ++i) { T e; St<T>::st(&e, v[i]); t[i] = e; }
+    *reinterpret_cast<typename Piece<T>::vec*>(p) = t;
+}
+__device__ inline float lanes_sum(float v, int lpr) {
+    for (int o = 1; o < lpr; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <typename T> __device__ inline void ln_stats(const float v[Piece<T>::VW], int lpr, float invW, float& mean, float& rho) {
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < Piece<T>::VW; ++i) { s += v[i]; ss += v[i] * v[i]; }
+    s = lanes_sum(s, lpr); ss = lanes_sum(ss, lpr);
+    mean = s * invW;
+    rho = rsqrtf(fmaxf(0.f, ss * invW - mean * mean) + 1e-6f);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(AT) adaln_fwd_narrow_kernel(AdaArgs a, int lpr) {
+    constexpr int VW = Piece<T>::VW;
+    const int part = threadIdx.x % lpr;
+    const int64_t slots = (int64_t)gridDim.x * (AT / lpr);
+    const float invW = 1.0f / (float)a.W;
+    for (int64_t row = blockIdx.x * (int64_t)(AT / lpr) + threadIdx.x / lpr; row < a.rows; row += slots) {
+        const bool tan = row >= a.act_rows;
+        const int64_t prow = tan ? row - a.act_rows : row;
+        float x[VW], sc[VW], sh[VW], y[VW];
+        ld_piece<T>((const T*)a.x + prow * a.ldx + part * VW, x);
+        ld_piece<T>((const T*)a.scale + (prow / a.mod_div) * a.ldm + part * VW, sc);
+        float mean, rho;
+        ln_stats<T>(x, lpr, invW, mean, rho);
+        if (!tan) {
+            ld_piece<T>((const T*)a.shift + (prow / a.mod_div) * a.ldm + part * VW, sh);
+#pragma unroll
+            for (int i = 0; i < VW; ++i) y[i] = (1.0f + sc[i]) * ((x[i] - mean) * rho) + sh[i];
+        } else {
+            float xd[VW], scd[VW], shd[VW];
+            ld_piece<T>((const T*)a.x + row * a.ldx + part * VW, xd);
+            ld_piece<T>((const T*)a.scale + (row / a.mod_div) * a.ldm + part * VW, scd);
+            ld_piece<T>((const T*)a.shift + (row / a.mod_div) * a.ldm + part * VW, shd);
+            float sd = 0.f;
+#pragma unroll
+            for (int i = 0; i < VW; ++i) sd += xd[i];
+            const float md = lanes_sum(sd, lpr) * invW;
+            float dt = 0.f;
+#pragma unroll
+            for (int i = 0; i < VW; ++i) dt += (x[i] - mean) * rho * (xd[i] - md);
+            const float dot = lanes_sum(dt, lpr) * invW;
+#pragma unroll
+            for (int i = 0; i < VW; ++i) {
+                const float n = (x[i] - mean) * rho;
+                const float nd = rho * (xd[i] - md - n * dot);
+                y[i] = scd[i] * n + (1.0f + sc[i]) * nd + shd[i];
+            }
+        }
+        st_piece<T>((T*)a.y + row * a.ldy + part * VW, y);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(AT) adaln_bwd_narrow_kernel(AdaArgs a, int lpr) {
+    constexpr int VW = Piece<T>::VW;
+    const int part = threadIdx.x % lpr;
+    const int64_t slots = (int64_t)gridDim.x * (AT / lpr);
+    const float invW = 1.0f / (float)a.W;
+    for (int64_t row = blockIdx.x * (int64_t)(AT / lpr) + threadIdx.x / lpr; row < a.rows; row += slots) {
+        float x[VW], sc[VW], dy[VW], dx[VW];
+        ld_piece<T>((const T*)a.x + row * a.ldx + part * VW, x);
+        ld_piece<T>((const T*)a.scale + (row / a.mod_div) * a.ldm + part * VW, sc);
+        ld_piece<T>((const T*)a.dy + row * a.ldy + part * VW, dy);
+        float mean, rho;
+        ln_stats<T>(x, lpr, invW, mean, rho);
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VW; ++i) {
+            const float n = (x[i] - mean) * rho, dn = dy[i] * (1.0f + sc[i]);
+            m1 += dn; m2 += dn * n;
+        }
+        m1 = lanes_sum(m1, lpr) * invW;
+        m2 = lanes_sum(m2, lpr) * invW;
+        float ds[VW];
+#pragma unroll
+        for (int i = 0; i < VW; ++i) {
+            const float n = (x[i] - mean) * rho, dn = dy[i] * (1.0f + sc[i]);
+            dx[i] = rho * (dn - m1 - n * m2);
+            ds[i] = dy[i] * n;
+        }
+        st_piece<T>((T*)a.dx + row * a.ldx + part * VW, dx);
+        if (a.mod_div == 1) {
+            st_piece<T>((T*)a.dscale + row * a.ldd + part * VW, ds);
+            st_piece<T>((T*)a.dshift + row * a.ldd + part * VW, dy);
+        }
+    }
+}
+
+// dscale / dshift of a modulation shared by mod_div rows, narrow rows: one workgroup per group, its AT / LPR row slots
+// stride the group's rows (ascending), and the slots' partial sums are added in slot order -- bitwise reproducible.
+template <typename T>
+__global__ void __launch_bounds__(AT) adaln_bwd_mod_narrow_kernel(AdaArgs a, int lpr) {
+    constexpr int VW = Piece<T>::VW;
+    __shared__ float red[2][AT * VW];
+    const int part = threadIdx.x % lpr, slot = threadIdx.x / lpr, nslot = AT / lpr;
+    const int64_t grp = blockIdx.x;
+    const int64_t r0 = grp * a.mod_div, r1 = (r0 + a.mod_div < a.rows) ? r0 + a.mod_div : a.rows;
+    const float invW = 1.0f / (float)a.W;
+    float as[VW], ah[VW];
+#pragma unroll
+    for (int i = 0; i < VW; ++i) { as[i] = 0.f; ah[i] = 0.f; }
+    for (int64_t row = r0 + slot; row < r1; row += nslot) {
+        float x[VW], dy[VW];
+        ld_piece<T>((const T*)a.x + row * a.ldx + part * VW, x);
+        ld_piece<T>((const T*)a.dy + row * a.ldy + part * VW, dy);
+        float mean, rho;
+        ln_stats<T>(x, lpr, invW, mean, rho);
+#pragma unroll
+        for (int i = 0; i < VW; ++i) { as[i] += dy[i] * ((x[i] - mean) * rho); ah[i] += dy[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < VW; ++i) { red[0][threadIdx.x * VW + i] = as[i]; red[1][threadIdx.x * VW + i] = ah[i]; }
+    __syncthreads();
+    if (threadIdx.x < 2 * a.W) {
+        const int which = threadIdx.x >= a.W, c = threadIdx.x - which * (int)a.W;
+        const int pc = c / VW, ic = c % VW;
+        float sum = 0.f;
+        for (int k = 0; k < nslot; ++k) sum += red[which][(k * lpr + pc) * VW + ic];
+        ((float*)(which ? a.dshift : a.dscale))[grp * a.ldd + c] = sum;
+    }
+}
+
+inline bool narrow_ok(int dtype, int64_t W, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs, int& lpr) {
+    const int64_t es = dtype == MFC_F32 ? 4 : 2;
+    const int64_t bytes = W * es;
+    if (bytes % 16 || bytes > 256) return false;
+    lpr = (int)(bytes / 16);
+    if (lpr & (lpr - 1)) return false;
+    for (int64_t ld : lds) if ((ld * es) % 16) return false;
+    for (const void* p : ptrs) if ((uintptr_t)p % 16) return false;
+    return true;
+}
+
 struct GateArgs {
     int64_t rows, act_rows, W, ldo, ldm, ldr, ldy;
     const void* o; const void* s2; const void* res; void* y;
@@ -255,6 +411,13 @@ extern "C" int mfc_adaln_fwd(int dtype, int64_t rows, int64_t act_rows, int64_t 
     a.rows = rows; a.act_rows = act_rows; a.W = W; a.ldx = ldx; a.ldm = ldm; a.ldy = ldy; a.mod_div = mod_div;
     a.x = x; a.scale = scale; a.shift = shift; a.y = y;
     hipStream_t st = (hipStream_t)stream;
+    int lpr = 0;
+    if (rows >= 1024 && narrow_ok(dtype, W, {ldx, ldm, ldy}, {x, scale, shift, y}, lpr)) {
+        const unsigned grid = grid1d(rows * lpr);
+        if (dtype == MFC_F32) hipLaunchKernelGGL(adaln_fwd_narrow_kernel<float>, dim3(grid), dim3(AT), 0, st, a, lpr);
+        else hipLaunchKernelGGL(adaln_fwd_narrow_kernel<u16>, dim3(grid), dim3(AT), 0, st, a, lpr);
+        return mfc_launch_status();
+    }
     if (dtype == MFC_F32) hipLaunchKernelGGL(adaln_fwd_kernel<float>, dim3((unsigned)rows), dim3(AT), 0, st, a);
     else hipLaunchKernelGGL(adaln_fwd_kernel<u16>, dim3((unsigned)rows), dim3(AT), 0, st, a);
     return mfc_launch_status();
@@ -269,6 +432,20 @@ extern "C" int mfc_adaln_bwd(int dtype, int64_t rows, int64_t W, const void* x, 
     a.rows = rows; a.W = W; a.ldx = ldx; a.ldm = ldm; a.ldy = ldy; a.mod_div = mod_div; a.ldd = ldd;
     a.x = x; a.scale = scale; a.dy = dy; a.dx = dx; a.dscale = dscale; a.dshift = dshift;
     hipStream_t st = (hipStream_t)stream;
+    int lpr = 0;
+    // (mod_div == 1: dscale / dshift are [rows, W] in `dtype`; mod_div > 1: fp32 [groups, W] -- 16-byte pieces of fp32 need W % 4)
+    if (rows >= 1024 && narrow_ok(dtype, W, {ldx, ldm, ldy, mod_div == 1 ? ldd : 0}, {x, scale, dy, dx, mod_div == 1 ? dscale : nullptr,
+                                  mod_div == 1 ? dshift : nullptr}, lpr) && 2 * W <= AT) {
+        const unsigned grid = grid1d(rows * lpr);
+        if (dtype == MFC_F32) hipLaunchKernelGGL(adaln_bwd_narrow_kernel<float>, dim3(grid), dim3(AT), 0, st, a, lpr);
+        else hipLaunchKernelGGL(adaln_bwd_narrow_kernel<u16>, dim3(grid), dim3(AT), 0, st, a, lpr);
+        if (mod_div > 1) {
+            const unsigned groups = (unsigned)((rows + mod_div - 1) / mod_div);
+            if (dtype == MFC_F32) hipLaunchKernelGGL(adaln_bwd_mod_narrow_kernel<float>, dim3(groups), dim3(AT), 0, st, a, lpr);
+            else hipLaunchKernelGGL(adaln_bwd_mod_narrow_kernel<u16>, dim3(groups), dim3(AT), 0, st, a, lpr);
+        }
+        return mfc_launch_status();
+    }
     if (dtype == MFC_F32) hipLaunchKernelGGL(adaln_bwd_kernel<float>, dim3((unsigned)rows), dim3(AT), 0, st, a);
     else hipLaunchKernelGGL(adaln_bwd_kernel<u16>, dim3((unsigned)rows), dim3(AT), 0, st, a);
     if (mod_div > 1) {

@@ -1659,9 +1659,9 @@ cnx_bwd_n1_kernel(PixArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, m = lane & 15;
-    // LDS: per wave [6][16][CS] transpose scratch (MODE 1), then the cross-wave flush scratch
-    T* wsT = reinterpret_cast<T*>(smem) + (size_t)wave * WS_TILES * 16 * CS;
-    float* red = reinterpret_cast<float*>(smem + (((size_t)NWAVES * WS_TILES * 16 * CS * sizeof(T)) + 15) / 16 * 16);
+    // LDS: per wave 2 x [6][16][CS] transpose scratch (MODE 1: double-buffered), then the cross-wave flush scratch
+    T* wsT = reinterpret_cast<T*>(smem) + (size_t)wave * 2 * WS_TILES * 16 * CS;
+    float* red = reinterpret_cast<float*>(smem + (MODE == 1 ? (((size_t)NWAVES * 2 * WS_TILES * 16 * CS * sizeof(T)) + 15) / 16 * 16 : 0));
     FwdW<T> w;
     w.load(a.p, q, m);
     const T* pw = (const T*)a.p.con_w;  // [32][16]: dy[e] = sum_c Wp[e][c] ls[c] dout[c]
@@ -1728,6 +1728,19 @@ cnx_bwd_n1_kernel(PixArgs a) {
             rho = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                       make_rsrc(a.rho1 + rr * npix, (uint32_t)(npix * sizeof(float))), roff_of(jj), 0, 0));
     };
+    auto wgrad_from = [&](const T* wb) {
+        const frag_t tdo = pix_k_frag<T>(wb + 2 * 16 * CS, q, m);
+        const frag_t tn1 = pix_k_frag<T>(wb + 3 * 16 * CS, q, m);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const frag_t ty = pix_k_frag<T>(wb + jj * 16 * CS, q, m);
+            const frag_t tde = pix_k_frag<T>(wb + (4 + jj) * 16 * CS, q, m);
+            mma16(aWp[jj], ty, tdo);    // M[e][c] += y^T dout
+            mma16(aWe[jj], tn1, tde);   // [c][e] += n1^T de
+        }
+        mma16(aS, ones, tdo);           // every row: sum_p dout[p][c]
+        lds_fence();
+    };
     frag_t nn, dn;
     float rn = 0.f;
     if (t0 < t1) fetch(r, j, nn, dn, rn);
@@ -1792,26 +1805,24 @@ cnx_bwd_n1_kernel(PixArgs a) {
             const f32x4 dc4 = (fma4(n4, splat4(m2 * (-1.0f / 16.0f)), dn1) - splat4(m1 * (1.0f / 16.0f))) * splat4(rho1);
             float dc[4] = {dc4[0], dc4[1], dc4[2], dc4[3]};
             buf_st4(rs_dc, goff, dc, (const T*)nullptr);
-            // weight gradients contract over the 16 pixels of the wave row: one batched transpose through the wave scratch
-            *reinterpret_cast<frag_t*>(wsT + (0 * 16 + m) * CS + 4 * q) = yf[0];
-            *reinterpret_cast<frag_t*>(wsT + (1 * 16 + m) * CS + 4 * q) = yf[1];
-            *reinterpret_cast<frag_t*>(wsT + (2 * 16 + m) * CS + 4 * q) = dof;
-            *reinterpret_cast<frag_t*>(wsT + (3 * 16 + m) * CS + 4 * q) = n1f;     // (rows outside the image meet de = 0)
-            *reinterpret_cast<frag_t*>(wsT + (4 * 16 + m) * CS + 4 * q) = def[0];
-            *reinterpret_cast<frag_t*>(wsT + (5 * 16 + m) * CS + 4 * q) = def[1];
-            lds_fence();
-            const frag_t tdo = pix_k_frag<T>(wsT + 2 * 16 * CS, q, m);
-            const frag_t tn1 = pix_k_frag<T>(wsT + 3 * 16 * CS, q, m);
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const frag_t ty = pix_k_frag<T>(wsT + jj * 16 * CS, q, m);
-                const frag_t tde = pix_k_frag<T>(wsT + (4 + jj) * 16 * CS, q, m);
-                mma16(aWp[jj], ty, tdo);    // M[e][c] += y^T dout
-                mma16(aWe[jj], tn1, tde);   // [c][e] += n1^T de
-            }
-            mma16(aS, ones, tdo);           // every row: sum_p dout[p][c]
+            // Weight gradients contract over the 16 pixels of the wave row: one batched transpose (pixel-on-lane ->
+            // pixel-as-k) through the wave's LDS scratch.  The scratch is double-buffered and the transposed reads run ONE
+            // STEP BEHIND the writes: the tiles read here were written a whole step ago, so neither the LDS turnaround nor
+            // the accumulating MFMAs sit on this step's dependency chain (a wave's LDS operations execute in order).
+            T* wcur = wsT + ((t - t0) & 1) * (WS_TILES * 16 * CS);
+            const T* wprev = wsT + (((t - t0) & 1) ^ 1) * (WS_TILES * 16 * CS);
+            if (t > t0) wgrad_from(wprev);
+            *reinterpret_cast<frag_t*>(wcur + (0 * 16 + m) * CS + 4 * q) = yf[0];
+            *reinterpret_cast<frag_t*>(wcur + (1 * 16 + m) * CS + 4 * q) = yf[1];
+            *reinterpret_cast<frag_t*>(wcur + (2 * 16 + m) * CS + 4 * q) = dof;
+            *reinterpret_cast<frag_t*>(wcur + (3 * 16 + m) * CS + 4 * q) = n1f;     // (rows outside the image meet de = 0)
+            *reinterpret_cast<frag_t*>(wcur + (4 * 16 + m) * CS + 4 * q) = def[0];
+            *reinterpret_cast<frag_t*>(wcur + (5 * 16 + m) * CS + 4 * q) = def[1];
             lds_fence();
         }
+    }
+    if constexpr (MODE == 1) {
+        if (t0 < t1) wgrad_from(wsT + ((t1 - 1 - t0) & 1) * (WS_TILES * 16 * CS));     // the last step's tiles
     }
     if (rcur >= 0) flush_row();
     if constexpr (MODE == 0) {
@@ -1862,8 +1873,9 @@ cnx_bwd_n1_kernel(PixArgs a) {
         for (int i = threadIdx.x; i < REC_MAIN; i += NT) rec[i] = ABL_NO_FLUSH ? 0.f : scratch[i];
     }
 }
-template <typename T> inline size_t lds_bwd_n1_bytes() {
-    return (((size_t)NWAVES * WS_TILES * 16 * CS * sizeof(T)) + 15) / 16 * 16 + (size_t)REC_MAIN * sizeof(float);
+template <typename T> inline size_t lds_bwd_n1_bytes(int mode) {
+    if (mode == 0) return (size_t)NWAVES * REC_DQ * sizeof(float);
+    return (((size_t)NWAVES * 2 * WS_TILES * 16 * CS * sizeof(T)) + 15) / 16 * 16 + (size_t)REC_MAIN * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------
@@ -2157,8 +2169,8 @@ extern "C" int mfc_cnx_bwd_stats_n1(int dtype, int64_t R, int s, const void* n1,
     a.geo = make_pix_geo(R, s, max_blocks(K_BWD_STATS_N1), grid);
     a.n1 = n1; a.dout = dout; a.p = to_dev(p); a.q = q; a.ws = ws;
     hipStream_t st = (hipStream_t)stream;
-    int rc = dtype == MFC_F32 ? launch_k(cnx_bwd_n1_kernel<float, 0>, grid, lds_bwd_n1_bytes<float>(), st, a)
-                              : launch_k(cnx_bwd_n1_kernel<u16, 0>, grid, lds_bwd_n1_bytes<u16>(), st, a);
+    int rc = dtype == MFC_F32 ? launch_k(cnx_bwd_n1_kernel<float, 0>, grid, lds_bwd_n1_bytes<float>(0), st, a)
+                              : launch_k(cnx_bwd_n1_kernel<u16, 0>, grid, lds_bwd_n1_bytes<u16>(0), st, a);
     if (!rc) rc = reduce_rows(ws, a.geo, REC_DQ, 0, 32, 32, dq, nullptr, st);
     return rc;
 }
@@ -2174,8 +2186,8 @@ extern "C" int mfc_cnx_bwd_main_n1(int dtype, int64_t R, int s, const void* n1, 
     a.geo = make_pix_geo(R, s, max_blocks(K_BWD_MAIN_N1), grid);
     a.n1 = n1; a.rho1 = rho1; a.dout = dout; a.p = to_dev(p); a.q = q; a.kG = kG; a.dc1 = dc1; a.ws = ws;
     hipStream_t st = (hipStream_t)stream;
-    int rc = dtype == MFC_F32 ? launch_k(cnx_bwd_n1_kernel<float, 1>, grid, lds_bwd_n1_bytes<float>(), st, a)
-                              : launch_k(cnx_bwd_n1_kernel<u16, 1>, grid, lds_bwd_n1_bytes<u16>(), st, a);
+    int rc = dtype == MFC_F32 ? launch_k(cnx_bwd_n1_kernel<float, 1>, grid, lds_bwd_n1_bytes<float>(1), st, a)
+                              : launch_k(cnx_bwd_n1_kernel<u16, 1>, grid, lds_bwd_n1_bytes<u16>(1), st, a);
     if (!rc) {
         RedSegs sg = {{{g->con_w, 0, 512}, {g->exp_w, 512, 1024}, {g->ls, 1024, 1040}, {g->exp_b, 1040, 1072}}, 4};
         rc = reduce_blocks(ws, grid, REC_MAIN, REC_MAIN, sg, st);
