@@ -310,7 +310,8 @@ int mfc_gelu_bwd(int dtype, int64_t n, const void* pre, const void* dout, void* 
  * meanflow_audio_codec/utils.py:16-25).
  *  kind 0: delta = u + (t-r) dudt - target        (iMF; FM with dudt == NULL)
  *  kind 1: delta = u - (target - clip(t-r,0,1) dudt)   (MeanFlow)
- *  only rows < n_tan carry a tangent (rows with r == t multiply it by 0).
+ *  only n_tan rows carry a tangent (rows with r == t multiply it by 0): n_tan >= 0: the FIRST n_tan rows, dudt row b;
+ *  n_tan < 0 (ABI 3): the LAST -n_tan rows, dudt row b - (B + n_tan).
  *  mode 0: weighted L2  w=sg(1/(pe+c)^p), loss=mean(w pe); mode 1: MSE; mode 2: MeanFlow
  *  adaptive weight on the per-example MEAN square, exponent p = 1-gamma.
  * Means are over Bglobal (data-parallel shards pass their local B rows).

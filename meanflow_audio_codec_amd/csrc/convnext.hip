@@ -1782,16 +1782,21 @@ cnx_bwd_n1_kernel(PixArgs a) {
             for (int jj = 0; jj < 2; ++jj) dqp[jj] = fma4(dy[jj], g[jj], dqp[jj]);
         } else {
             // the pixels past the end of the image (last step of an image only) must not reach d exp_b: g != 0 there
-            f32x4 kge[2] = {kg[0], kg[1]};
-            if (jt == spi - 1 && goff == BUF_OOB) { kge[0] = z4; kge[1] = z4; }
             frag_t yf[2], def[2];
+            f32x4 de[2];
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const f32x4 yv = fma4(g[jj], gq[jj], bet4[jj]);
                 make_frag(yf[jj], yv[0], yv[1], yv[2], yv[3]);
-                const f32x4 de = fma4(dy[jj], gq[jj], g[jj] * kge[jj]) * gp[jj];
-                dbe[jj] = dbe[jj] + de;
-                make_frag(def[jj], de[0], de[1], de[2], de[3]);
+                de[jj] = fma4(dy[jj], gq[jj], g[jj] * kg[jj]) * gp[jj];
+                dbe[jj] = dbe[jj] + de[jj];
+                make_frag(def[jj], de[0 + jj][0], de[jj][1], de[jj][2], de[jj][3]);
+            }
+            // The pixels past the end of the image (last step of an image only: n1 = dout = 0 there, but g(be) != 0) must
+            // not reach d exp_b -- everything else they touch is multiplied by a zero or never stored.  Taken back here,
+            // in a branch the other 6000 steps of the image skip.
+            if (jt == spi - 1) [[unlikely]] {
+                if (goff == BUF_OOB) { dbe[0] = dbe[0] - de[0]; dbe[1] = dbe[1] - de[1]; }
             }
             f32x4 dn1 = z4;
             mma_pair(dn1, weT[0], weT[1], def[0], def[1]);      // dn1^T = We de^T

@@ -187,19 +187,19 @@ __global__ void gelu_bwd_kernel(int64_t n, const T* pre, const T* dout, T* din) 
 // pe[b] = sum_d delta^2: workgroup (x, b) stores its partial sum in part[b * gridDim.x + x]; loss_finalize_kernel adds
 // the partials of an example in ascending x (fixed order, no atomics: the loss weight 1/(pe + c) feeds every gradient)
 template <typename T>
-__global__ void loss_pe_kernel(int kind, int64_t B, int64_t D, const T* u, const T* dudt, int64_t n_tan,
+__global__ void loss_pe_kernel(int kind, int64_t B, int64_t D, const T* u, const T* dudt, int64_t tan0, int64_t n_tan,
                                const float* t, const float* r, const float* target, float* part) {
     __shared__ float red[ET / 64];
     const int64_t b = blockIdx.y;
     float coef = 0.f;
-    if (dudt && b < n_tan) {
+    if (dudt && b >= tan0 && b < tan0 + n_tan) {
         coef = t[b] - r[b];
         if (kind == 1) coef = fminf(fmaxf(coef, 0.f), 1.f);
     }
     float acc = 0.f;
     for (int64_t d = blockIdx.x * (int64_t)ET + threadIdx.x; d < D; d += (int64_t)gridDim.x * ET) {
         float v = St<T>::ld(u + b * D + d) - target[b * D + d];
-        if (coef != 0.f) v += coef * St<T>::ld(dudt + b * D + d);
+        if (coef != 0.f) v += coef * St<T>::ld(dudt + (b - tan0) * D + d);
         acc += v * v;
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -252,16 +252,16 @@ __global__ void loss_finalize_kernel(int mode, int64_t B, int64_t Bglobal, int64
 
 // du[b,d] = seed[b] * delta[b,d]
 template <typename T>
-__global__ void loss_grad_kernel(int kind, int64_t B, int64_t D, const T* u, const T* dudt, int64_t n_tan,
+__global__ void loss_grad_kernel(int kind, int64_t B, int64_t D, const T* u, const T* dudt, int64_t tan0, int64_t n_tan,
                                  const float* t, const float* r, const float* target, const float* seed, T* du) {
     const int64_t total = B * D;
     for (int64_t o = blockIdx.x * (int64_t)ET + threadIdx.x; o < total; o += (int64_t)gridDim.x * ET) {
         const int64_t b = o / D;
         float v = St<T>::ld(u + o) - target[o];
-        if (dudt && b < n_tan) {
+        if (dudt && b >= tan0 && b < tan0 + n_tan) {
             float coef = t[b] - r[b];
             if (kind == 1) coef = fminf(fmaxf(coef, 0.f), 1.f);
-            v += coef * St<T>::ld(dudt + o);
+            v += coef * St<T>::ld(dudt + o - tan0 * D);
         }
         St<T>::st(du + o, seed[b] * v);
     }
@@ -489,7 +489,10 @@ extern "C" int mfc_flow_loss(int dtype, int kind, int mode, int64_t B, int64_t B
                              void* du, float* ws, void* stream) {
     if (!u || !target || !pe || !seed || !loss || !ws) return MFC_EFAULT;
     if (dudt && (!t || !r)) return MFC_EFAULT;
-    if (B <= 0 || D <= 0 || Bglobal < B || n_tan < 0 || n_tan > B || !DT_OK(dtype)) return MFC_EINVAL;
+    if (B <= 0 || D <= 0 || Bglobal < B || n_tan < -B || n_tan > B || !DT_OK(dtype)) return MFC_EINVAL;
+    // n_tan >= 0: the FIRST n_tan rows carry a tangent (dudt row b); n_tan < 0: the LAST -n_tan rows do (dudt row b - (B + n_tan))
+    const int64_t tan0 = n_tan >= 0 ? 0 : B + n_tan;
+    if (n_tan < 0) n_tan = -n_tan;
     if (kind < 0 || kind > 1 || mode < 0 || mode > 2 || B > 65535) return MFC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     int64_t gx = ceil_div64(D, ET * 8);
@@ -497,19 +500,19 @@ extern "C" int mfc_flow_loss(int dtype, int kind, int mode, int64_t B, int64_t B
     dim3 g1((unsigned)gx, (unsigned)B);
     if (dtype == MFC_F32)
         hipLaunchKernelGGL(loss_pe_kernel<float>, g1, dim3(ET), 0, st, kind, B, D, (const float*)u,
-                           (const float*)dudt, n_tan, t, r, target, ws);
+                           (const float*)dudt, tan0, n_tan, t, r, target, ws);
     else
         hipLaunchKernelGGL(loss_pe_kernel<u16>, g1, dim3(ET), 0, st, kind, B, D, (const u16*)u, (const u16*)dudt,
-                           n_tan, t, r, target, ws);
+                           tan0, n_tan, t, r, target, ws);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, mode, B, Bglobal, D, (const float*)ws, (int)gx,
                        pe, p, c, seed, loss);
     if (du) {
         if (dtype == MFC_F32)
             hipLaunchKernelGGL(loss_grad_kernel<float>, dim3(grid_for(B * D)), dim3(ET), 0, st, kind, B, D,
-                               (const float*)u, (const float*)dudt, n_tan, t, r, target, seed, (float*)du);
+                               (const float*)u, (const float*)dudt, tan0, n_tan, t, r, target, seed, (float*)du);
         else
             hipLaunchKernelGGL(loss_grad_kernel<u16>, dim3(grid_for(B * D)), dim3(ET), 0, st, kind, B, D,
-                               (const u16*)u, (const u16*)dudt, n_tan, t, r, target, seed, (u16*)du);
+                               (const u16*)u, (const u16*)dudt, tan0, n_tan, t, r, target, seed, (u16*)du);
     }
     return mfc_launch_status();
 }

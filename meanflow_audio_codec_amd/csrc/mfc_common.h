@@ -99,7 +99,7 @@ __device__ inline void gelu_both4(f32x4 x, f32x4& g, f32x4& dg) {
     const f32x4 sg = gelu_sig4(x);
     const f32x4 da2 = fma4(x * splat4(2.0f * MFC_GELU_K0 * 3.0f * MFC_GELU_K1), x, splat4(2.0f * MFC_GELU_K0));
     g = x * sg;
-    dg = fma4(g * (splat4(1.0f) - sg), da2, sg);
+    dg = fma4(fma4(g, -sg, g), da2, sg);      // sg + g (1 - sg) da2; the negation is a source modifier of the packed fma
 }
 // second derivative, needed for d/dx of (t * gelu'(x)) in the tangent's backward
 // (not on the iMF path: the tangent carries no gradient) -- kept out.

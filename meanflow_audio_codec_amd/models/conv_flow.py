@@ -32,7 +32,7 @@ BOTTLENECK = 128  # models/conv_flow.py:142,153
 class ConvCtx:
     """Saved primal activations of one forward pass (consumed by ``backward``)."""
     __slots__ = ("R", "x_in", "a1", "g1", "a2", "g2", "H0", "rho", "O", "G", "q", "sc", "sh", "cond", "lat", "enc", "N1",
-                 "rho1")
+                 "rho1", "stride")
 
     def __init__(self):
         for k in self.__slots__:
@@ -188,7 +188,7 @@ class ConditionalConvFlow:
         n_tan = 0 if xdot is None else xdot.shape[0]
         assert n_tan <= R
         Rt = R + n_tan
-        K, S, s, dev, T = self.num_blocks, self.S, self.spatial_size, x.device, self.dtype
+        K, S, dev, T = self.num_blocks, self.S, x.device, self.dtype
         keep_n1 = self.use_grn and self.keep_n1
         X = self._buf(("X0", Rt), (Rt, D), T, dev) if not save else torch.empty((Rt, D), dtype=T, device=dev)
         X[:R].copy_(x)
@@ -209,25 +209,44 @@ class ConditionalConvFlow:
             ctx.H0 = self._buf(("H0save", R, n_tan), (K * R + n_tan, S), T, dev)    # holds h1 = LN(h0) (primal rows)
             ctx.O = self._buf(("Osave", R, n_tan), (K * R + n_tan, S), T, dev)
             ctx.rho = self._buf(("rhosave", R), (K, R, S // 16), torch.float32, dev)
+            ctx.stride = R
             if keep_n1:
                 # n1 = LN(conv(FiLM(h1))) and its 1/sigma of every block's primal rows, written by the statistics pass:
                 # the apply pass and the reverse pass start from them (ops.cnx_forward keep= / cnx_backward n1=)
                 ctx.N1 = self._buf(("N1save", R), (K * R, S), T, dev)
                 ctx.rho1 = self._buf(("rho1save", R), (K, R, S // 16), torch.float32, dev)
+
+            def bufs(i):
+                return (ctx.H0[i * R:i * R + Rt], ctx.O[i * R:i * R + Rt], ctx.rho[i],
+                        ctx.N1[i * R:(i + 1) * R] if keep_n1 else None, ctx.rho1[i].view(R, -1) if keep_n1 else None)
+
+            def record(i, X_in, a1, g1, a2, g2, G, q, sc, sh):
+                ctx.x_in.append(X_in); ctx.a1.append(a1); ctx.g1.append(g1); ctx.a2.append(a2); ctx.g2.append(g2)
+                ctx.G.append(G); ctx.q.append(q); ctx.sc.append(sc); ctx.sh.append(sh)
         else:
             H0s = self._buf(("H0", Rt), (Rt, S), T, dev)
             Os = self._buf(("O", Rt), (Rt, S), T, dev)
             rhos = self._buf(("rho", R), (R, S // 16), torch.float32, dev)
-            if keep_n1:
-                N1s = self._buf(("N1", R), (R, S), T, dev)
-                rho1s = self._buf(("rho1", R), (R, S // 16), torch.float32, dev)
+            N1s = self._buf(("N1", R), (R, S), T, dev) if keep_n1 else None
+            rho1s = self._buf(("rho1", R), (R, S // 16), torch.float32, dev) if keep_n1 else None
+            bufs = lambda i: (H0s, Os, rhos, N1s, rho1s)
+            record = None
+        X = self._run_blocks(w, X, cstack, R, n_tan, bufs, record, save)
+        out = X[:R]
+        outdot = X[R:] if n_tan else None
+        return out, outdot, ctx
+
+    def _run_blocks(self, w, X, cstack, R, n_tan, bufs, record, fresh_x):
+        """The K blocks on the row-stacked [primal (R); tangent (n_tan)] batch ``X``.  ``bufs(i)`` -> (H0 [Rt,S],
+        O [Rt,S], rho [R, s*s], N1 [R,S] | None, rho1 [R, s*s] | None) of block i; ``record(i, ...)`` keeps what the
+        reverse pass needs; ``fresh_x``: every block output gets its own tensor (it is a saved block input)."""
+        K, S, s, dev, T, D = self.num_blocks, self.S, self.spatial_size, X.device, self.dtype, self.noise_dimension
+        Rt = R + n_tan
         for i in range(K):
             b = f"blocks_{i}"
             a1 = dense(X, w[f"{b}/input_proj1/kernel"], w[f"{b}/input_proj1/bias"], bias_rows=R)
             g1 = ops.gelu_fwd(a1, act_rows=R)
-            H0 = ctx.H0[i * R:i * R + Rt] if save else H0s
-            O = ctx.O[i * R:i * R + Rt] if save else Os
-            rho = ctx.rho[i] if save else rhos
+            H0, O, rho, N1, r1 = bufs(i)
             # h0 = g1 W2 + b2 with the block's first LayerNorm fused into the epilogue: the primal rows of H0
             # hold h1 = LN(h0), rho its per-pixel 1/sigma; the tangent rows get the tangent of that LayerNorm
             ops.gemm(g1, w[f"{b}/input_proj2/kernel"], bias=w[f"{b}/input_proj2/bias"], bias_rows=R, out=H0,
@@ -236,9 +255,7 @@ class ConditionalConvFlow:
             sc, sh = cp[:R, :16].contiguous(), cp[:R, 16:].contiguous()
             cw = self._cnx_w(w, i)
             Gs, qs = [], []
-            if keep_n1:
-                N1 = ctx.N1[i * R:(i + 1) * R] if save else N1s
-                r1 = (ctx.rho1[i] if save else rho1s).view(R, -1)
+            if N1 is not None:
                 N1d = self._buf(("N1dot", n_tan), (n_tan, S), T, dev) if n_tan else None     # tangent of n1: scratch
                 keep = lambda a, b: (N1[a:b], r1[a:b]) if a else (N1[a:b], r1[a:b], N1d)
             else:
@@ -255,18 +272,77 @@ class ConditionalConvFlow:
                 Gs.append(G); qs.append(q)
             a2 = dense(O, w[f"{b}/output_proj1/kernel"], w[f"{b}/output_proj1/bias"], bias_rows=R)
             g2 = ops.gelu_fwd(a2, act_rows=R)
-            Xn = torch.empty((Rt, D), dtype=T, device=dev) if save else self._buf(("X", i & 1, Rt), (Rt, D), T, dev)
+            Xn = torch.empty((Rt, D), dtype=T, device=dev) if fresh_x else self._buf(("X", i & 1, Rt), (Rt, D), T, dev)
             dense(g2, w[f"{b}/output_proj2/kernel"], w[f"{b}/output_proj2/bias"], bias_rows=R, out=Xn,
                   alpha=1.0 / K, residual=X, beta=1.0)
-            if save:
-                ctx.x_in.append(X); ctx.a1.append(a1); ctx.g1.append(g1); ctx.a2.append(a2); ctx.g2.append(g2)
-                ctx.G.append(torch.cat(Gs, 0) if len(Gs) > 1 else Gs[0])
-                ctx.q.append(torch.cat(qs, 0) if len(qs) > 1 else qs[0])
-                ctx.sc.append(sc); ctx.sh.append(sh)
+            if record is not None:
+                record(i, X, a1, g1, a2, g2, torch.cat(Gs, 0) if len(Gs) > 1 else Gs[0],
+                       torch.cat(qs, 0) if len(qs) > 1 else qs[0], sc, sh)
             X = Xn
-        out = X[:R]
-        outdot = X[R:] if n_tan else None
-        return out, outdot, ctx
+        return X
+
+    def forward_imf(self, w: dict, z: torch.Tensor, cond_u: torch.Tensor, cond_v: torch.Tensor, cdot: torch.Tensor,
+                    n_plain: int, ctx: ConvCtx | None = None):
+        """The two forward passes of the improved-MeanFlow loss (trainers/loss_strategies.py:253-270) with the rows that
+        need no tangent riding along with the boundary pass.  Rows of ``z`` / ``cond_u``: [plain (r == t): n_plain;
+        tangent: n_tan]; ``cond_v`` / ``cdot`` ([n_tan, cond]) belong to the tangent rows.
+
+          pass A (R rows, primal only):  [plain rows with cond_u ; tangent rows with cond_v]  ->  u_plain, v
+          pass B (n_tan + n_tan rows):   [tangent rows with cond_u ; their tangents (v, cdot)]  ->  u_tan, du/dt
+
+        instead of a 64-row boundary pass and a 192-row pass: every GEMM and ConvNeXt launch of the two passes works on
+        128 rows (B = 128, p = 0.5).  Returns (u [R, D] in the row order of ``z``, dudt [n_tan, D], ctx).  The saved
+        activations of all R rows end up in ONE context in that row order: a block's save region is
+        [plain | tangent-primal | tangent-tangent] (stride R + n_tan rows), pass A writes [plain | v rows] into its
+        first R rows, pass B then overwrites the v rows with its primal rows and appends its tangent rows."""
+        _lib.require_cuda(z, cond_u, cond_v)
+        R, D = z.shape
+        n_tan = R - n_plain
+        assert 0 < n_plain < R and cond_v.shape[0] == n_tan and cdot.shape[0] == n_tan and z.dtype == self.dtype
+        K, S, dev, T = self.num_blocks, self.S, z.device, self.dtype
+        keep_n1 = self.use_grn and self.keep_n1
+        Rs = R + n_tan                                           # rows of one block's save region
+        ctx = ctx or ConvCtx()
+        ctx.R, ctx.stride, ctx.cond = R, Rs, cond_u
+        ctx.H0 = self._buf(("H0save2", R, n_tan), (K * Rs, S), T, dev)
+        ctx.O = self._buf(("Osave2", R, n_tan), (K * Rs, S), T, dev)
+        ctx.rho = self._buf(("rhosave", R), (K, R, S // 16), torch.float32, dev)
+        if keep_n1:
+            ctx.N1 = self._buf(("N1save", R), (K * R, S), T, dev)
+            ctx.rho1 = self._buf(("rho1save", R), (K, R, S // 16), torch.float32, dev)
+        saved = []
+
+        # ---- pass A
+        def bufs_a(i):
+            return (ctx.H0[i * Rs:i * Rs + R], ctx.O[i * Rs:i * Rs + R], ctx.rho[i],
+                    ctx.N1[i * R:(i + 1) * R] if keep_n1 else None, ctx.rho1[i].view(R, -1) if keep_n1 else None)
+
+        def record_a(i, X_in, a1, g1, a2, g2, G, q, sc, sh):
+            saved.append([X_in, a1, g1, a2, g2, G, q, sc, sh])
+        XA = torch.empty((R, D), dtype=T, device=dev)
+        XA.copy_(z)
+        cond_a = torch.cat([cond_u[:n_plain], cond_v], 0).contiguous()
+        out_a = self._run_blocks(w, XA, cond_a, R, 0, bufs_a, record_a, True)
+        v = out_a[n_plain:]
+
+        # ---- pass B: its primal rows take the place of pass A's v rows in every saved tensor
+        def bufs_b(i):
+            lo = i * Rs + n_plain
+            return (ctx.H0[lo:lo + 2 * n_tan], ctx.O[lo:lo + 2 * n_tan], ctx.rho[i][n_plain:],
+                    ctx.N1[i * R + n_plain:(i + 1) * R] if keep_n1 else None,
+                    ctx.rho1[i].view(R, -1)[n_plain:] if keep_n1 else None)
+
+        def record_b(i, X_in, a1, g1, a2, g2, G, q, sc, sh):
+            for dst, src in zip(saved[i], (X_in, a1, g1, a2, g2, G, q, sc, sh)):
+                dst[n_plain:R].copy_(src[:n_tan])
+        XB = torch.empty((2 * n_tan, D), dtype=T, device=dev)
+        XB[:n_tan].copy_(z[n_plain:])
+        XB[n_tan:].copy_(v)
+        cond_b = torch.cat([cond_u[n_plain:], cdot], 0).contiguous()
+        out_b = self._run_blocks(w, XB, cond_b, n_tan, n_tan, bufs_b, record_b, True)
+        ctx.x_in, ctx.a1, ctx.g1, ctx.a2, ctx.g2, ctx.G, ctx.q, ctx.sc, ctx.sh = (list(c) for c in zip(*saved))
+        u = torch.cat([out_a[:n_plain], out_b[:n_tan]], 0)
+        return u, out_b[n_tan:], v, ctx
 
     def block_param_names(self, i: int) -> list:
         pre = f"blocks_{i}/"
@@ -301,7 +377,8 @@ class ConditionalConvFlow:
             b = f"blocks_{i}"
             x_in = ctx.x_in[i][:R]
             a1, g1, a2, g2 = ctx.a1[i][:R], ctx.g1[i][:R], ctx.a2[i][:R], ctx.g2[i][:R]
-            H0, O = ctx.H0[i * R:(i + 1) * R], ctx.O[i * R:(i + 1) * R]
+            st = ctx.stride or R                   # rows of one block's save region (forward: R; forward_imf: R + n_tan)
+            H0, O = ctx.H0[i * st:i * st + R], ctx.O[i * st:i * st + R]
             # out = (g2 W4 + b4)/K + x
             dg2 = dense_dx(dX, w[f"{b}/output_proj2/kernel"], alpha=1.0 / K)
             dw(f"{b}/output_proj2/kernel", g2, dX, 1.0 / K)

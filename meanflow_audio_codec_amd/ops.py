@@ -415,8 +415,8 @@ def flow_loss(u, target, *, dudt=None, n_tan=0, t=None, r=None, kind=0, mode=0, 
     """Returns (loss scalar tensor, du or None, per-example pe)."""
     B, D = u.shape
     assert u.is_contiguous() and target.shape == u.shape and target.dtype == torch.float32
-    if dudt is not None:
-        assert dudt.dtype == u.dtype and dudt.is_contiguous() and dudt.shape[0] >= n_tan and dudt.shape[1] == D
+    if dudt is not None:      # n_tan < 0: the LAST -n_tan rows carry the tangents (dudt row b - (B + n_tan))
+        assert dudt.dtype == u.dtype and dudt.is_contiguous() and dudt.shape[0] >= abs(n_tan) and dudt.shape[1] == D
     dev = u.device
     pe = torch.empty(B, dtype=torch.float32, device=dev)
     seed = torch.empty(B, dtype=torch.float32, device=dev)

@@ -23,6 +23,7 @@ the first half of the ranks only r == t rows (3 forward-equivalents) and the res
 """
 from __future__ import annotations
 
+import os
 from abc import ABC, abstractmethod
 
 import torch
@@ -42,6 +43,22 @@ def _prep_x(x):
     if x.dtype != torch.float32:
         x = x.float()
     return x.reshape(x.shape[0], -1).contiguous()
+
+
+def _order_rows_plain_first(t, r, B, row0, Bg, prop, sampled, row_stride=1):
+    """Permutation putting rows with r == t FIRST (the merged two-pass schedule of ``model.forward_imf``); returns
+    (perm | None, n_tan).  With sampled times the r == t rows already are a local prefix (utils.py:41-44 applied per
+    global row), so no permutation is needed at all."""
+    if sampled:
+        gsz = ops.data_size_of(Bg, prop)
+        ds = min(max(-((row0 - gsz) // row_stride), 0), B)
+        return None, B - ds
+    mask = (t.reshape(-1) != r.reshape(-1))
+    n_tan = int(mask.sum().item())
+    if n_tan == B or n_tan == 0:
+        return None, n_tan
+    perm = torch.argsort(mask.to(torch.int8), stable=True)
+    return (None if bool((perm == torch.arange(B, device=perm.device)).all()) else perm), n_tan
 
 
 def _order_rows(t, r, B, row0, Bg, prop, sampled, row_stride=1):
@@ -117,8 +134,14 @@ class _TwoTimeLoss(LossStrategy):
                                                        row_stride=row_stride)
         t = t.reshape(B, 1).float().contiguous()
         r = r.reshape(B, 1).float().contiguous()
-        perm, n_tan = _order_rows(t, r, B, row0, Bg, getattr(self.time_sampling, "data_proportion", 0.5), sampled,
-                                  row_stride)
+        prop = getattr(self.time_sampling, "data_proportion", 0.5)
+        if use_v_pass and hasattr(model, "forward_imf") and os.environ.get("MFC_IMF_MERGE", "1") != "0":
+            _, n_tan0 = _order_rows_plain_first(t, r, B, row0, Bg, prop, sampled, row_stride)
+            if 0 < n_tan0 < B:
+                return self._run_merged(state, key, x, e, t, r, row0, Bg, aux, nmin=nmin, nmax=nmax, mode=mode, p=p, c=c,
+                                        on_block=on_block, fused=fused, row_stride=row_stride, want_grads=want_grads,
+                                        sampled=sampled, prop=prop)
+        perm, n_tan = _order_rows(t, r, B, row0, Bg, prop, sampled, row_stride)
         prep = dict(seed=key.seed, step=key.counter)
         if perm is None:
             z, target, _ = ops.flow_prepare(x, t, model.dtype, nmin, nmax, e=e, row0=row0, row_stride=row_stride, **prep)
@@ -169,6 +192,45 @@ class _TwoTimeLoss(LossStrategy):
             un = (lambda a: a) if inv is None else (lambda a: a[inv])
             aux.update(u=un(u), t=un(t), r=un(r), n_tan=n_tan, per_example=un(pe),
                        dudt=dudt, perm=perm, v=(zdot if use_v_pass else None))
+        return loss, grads
+
+
+    def _run_merged(self, state, key, x, e, t, r, row0, Bg, aux, *, nmin, nmax, mode, p, c, on_block, fused, row_stride,
+                    want_grads, sampled, prop):
+        """improved MeanFlow with the model's two-pass schedule (``forward_imf``): rows are kept [r == t rows; tangent
+        rows] -- with sampled times that is the order the batch already has -- the boundary velocity pass carries the
+        r == t rows of the u pass along, and the tangent pass runs on the tangent rows alone.  Same arithmetic per row
+        as ``_run``; only the grouping of rows into launches differs."""
+        model, w = state.model, state.work
+        B = x.shape[0]
+        perm, n_tan = _order_rows_plain_first(t, r, B, row0, Bg, prop, sampled, row_stride)
+        n_plain = B - n_tan
+        prep = dict(seed=key.seed, step=key.counter)
+        z, target, _ = ops.flow_prepare(x, t, model.dtype, nmin, nmax, e=e, row0=row0, row_stride=row_stride, **prep)
+        if perm is not None:     # explicit (t, r) with r == t rows not in front: noise was drawn in the original order
+            x, t, r = x[perm].contiguous(), t[perm].contiguous(), r[perm].contiguous()
+            z, target = z[perm].contiguous(), target[perm].contiguous()
+        ctx_holder = model.new_ctx()
+        latents = model.encode(w, x, ctx_holder)
+        h = ops.axpby(1.0, t, -1.0, r)
+        cond_u, cdot = model.conditioning(w, t, h, latents, want_dot=True)
+        tt = t[n_plain:].contiguous()
+        lat_t = None if latents is None else latents[n_plain:]
+        cond_v, _ = model.conditioning(w, tt, torch.zeros_like(tt), lat_t)       # boundary velocity v = f(z, [t, 0])
+        u, dudt, v, ctx = model.forward_imf(w, z, cond_u, cond_v, cdot[n_plain:].contiguous(), n_plain, ctx=ctx_holder)
+        loss, du, pe = ops.flow_loss(u, target, dudt=dudt, n_tan=-n_tan, t=t, r=r, kind=self.kind, mode=mode, p=p, c=c,
+                                     Bglobal=Bg, want_grad=want_grads)
+        grads = None
+        if want_grads:
+            grads = state.grad_buffers()
+            _, dcond, dlat = model.backward(w, ctx, du, grads, on_block=on_block, fused=fused)
+            model.backward_conditioning(w, ctx, dcond, latents, grads, dlat=dlat)
+        if aux is not None:
+            inv = None if perm is None else torch.argsort(perm)
+            un = (lambda a: a) if inv is None else (lambda a: a[inv])
+            # ``dudt`` / ``v`` rows: the tangent rows in batch order (= rows n_plain.. of the permuted batch)
+            aux.update(u=un(u), t=un(t), r=un(r), n_tan=n_tan, per_example=un(pe), dudt=dudt, perm=perm, v=v,
+                       tangent_rows_last=True)
         return loss, grads
 
 

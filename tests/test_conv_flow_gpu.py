@@ -82,6 +82,46 @@ def test_improved_mean_flow_loss_and_grads(dtype, tol, gtol):
     assert abs(loss2.item() - loss2_ref.item()) < tol * max(1.0, abs(loss2_ref.item()))
 
 
+def test_merged_two_pass_schedule_equals_the_plain_one(monkeypatch):
+    """``model.forward_imf`` (the r == t rows ride along with the boundary velocity pass; the tangent pass runs on the
+    tangent rows alone) against the row-stacked schedule of ``_run``: the same arithmetic per row, other launch shapes
+    -- loss, u, du/dt, v and every gradient agree to fp32 rounding; rows in any order (explicit t, r), and the sampled
+    prefix rule."""
+    from meanflow_audio_codec_amd.trainers import ImprovedMeanFlowLoss, PRNGKey
+    model, state, pq = _make(torch.float32, seed=6)
+    x, e, t, r = _draws(7, seed=15)
+    r = r.clone()
+    r[1] = t[1]; r[4] = t[4]; r[5] = t[5]          # r == t rows scattered through the batch
+    outs = {}
+    for merge in ("1", "0"):
+        monkeypatch.setenv("MFC_IMF_MERGE", merge)
+        aux = {}
+        loss, grads = ImprovedMeanFlowLoss().compute_loss(state, PRNGKey(0), x.cuda(), e=e.cuda(), t=t.cuda(), r=r.cuda(), aux=aux)
+        outs[merge] = (loss.item(), {k: v.clone() for k, v in grads.items()}, {k: (v.clone() if torch.is_tensor(v) else v)
+                                                                               for k, v in aux.items()})
+        assert bool(aux.get("tangent_rows_last", False)) == (merge == "1")
+    (l1, g1, a1), (l0, g0, a0) = outs["1"], outs["0"]
+    assert a1["n_tan"] == a0["n_tan"] == 4
+    assert abs(l1 - l0) < 1e-6 * max(1.0, abs(l0))
+    for k in ("u", "dudt", "v", "per_example"):
+        assert _rel(a1[k], a0[k].double().cpu()) < 2e-5, k
+    bad = {k: _rel(g1[k], g0[k].double().cpu()) for k in g0 if g0[k].abs().max() > 0 and not _rel(g1[k], g0[k].double().cpu()) < 2e-4}
+    assert not bad, bad
+    # sampled times: the r == t rows are a prefix, no permutation in the merged schedule; both schedules draw the same noise
+    outs = {}
+    for merge in ("1", "0"):
+        monkeypatch.setenv("MFC_IMF_MERGE", merge)
+        aux = {}
+        loss, grads = ImprovedMeanFlowLoss().compute_loss(state, PRNGKey(3), x.cuda(), aux=aux)
+        outs[merge] = (loss.item(), {k: v.clone() for k, v in grads.items()}, aux)
+    assert outs["1"][2]["perm"] is None and outs["1"][2]["n_tan"] == outs["0"][2]["n_tan"] == 7 - int(7 * 0.5)
+    assert abs(outs["1"][0] - outs["0"][0]) < 1e-6 * max(1.0, abs(outs["0"][0]))
+    assert _rel(outs["1"][2]["u"], outs["0"][2]["u"].double().cpu()) < 2e-5
+    bad = {k: _rel(outs["1"][1][k], outs["0"][1][k].double().cpu()) for k in outs["0"][1]
+           if outs["0"][1][k].abs().max() > 0 and not _rel(outs["1"][1][k], outs["0"][1][k].double().cpu()) < 2e-4}
+    assert not bad, bad
+
+
 def test_jvp_matches_reverse_mode_property():
     """test/test_improved_mean_flow.py:57-100 restated on the HIP passes (fp32, 1e-4 relative):
     sum(dudt) for tangent (v, 1, 0) == <grad_z sum(u), v> + sum(grad_t sum(u))."""
