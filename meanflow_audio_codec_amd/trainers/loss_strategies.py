@@ -135,7 +135,11 @@ class _TwoTimeLoss(LossStrategy):
         t = t.reshape(B, 1).float().contiguous()
         r = r.reshape(B, 1).float().contiguous()
         prop = getattr(self.time_sampling, "data_proportion", 0.5)
-        if use_v_pass and hasattr(model, "forward_imf") and os.environ.get("MFC_IMF_MERGE", "1") != "0":
+        # Optional two-pass schedule (MFC_IMF_MERGE=1): measured on MI355X at the literal shape it is NOT faster than the
+        # row-stacked default (161.9 vs 160.1 ms per step: two 128-row N-streaming products cost as much as a 64-row and
+        # a 192-row one, and the ConvNeXt kernels are indifferent to the split), so it stays off; kept because it
+        # halves the largest activation batch (2 x 128 rows instead of 64 + 192).
+        if use_v_pass and hasattr(model, "forward_imf") and os.environ.get("MFC_IMF_MERGE", "0") == "1":
             _, n_tan0 = _order_rows_plain_first(t, r, B, row0, Bg, prop, sampled, row_stride)
             if 0 < n_tan0 < B:
                 return self._run_merged(state, key, x, e, t, r, row0, Bg, aux, nmin=nmin, nmax=nmax, mode=mode, p=p, c=c,

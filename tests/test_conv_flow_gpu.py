@@ -91,7 +91,8 @@ def test_merged_two_pass_schedule_equals_the_plain_one(monkeypatch):
     model, state, pq = _make(torch.float32, seed=6)
     x, e, t, r = _draws(7, seed=15)
     r = r.clone()
-    r[1] = t[1]; r[4] = t[4]; r[5] = t[5]          # r == t rows scattered through the batch
+    r[4] = t[4]; r[5] = t[5]                       # r == t rows scattered through the batch (besides _draws' prefix)
+    r[0] = 0.5 * t[0]                              # ... and a tangent row in front
     outs = {}
     for merge in ("1", "0"):
         monkeypatch.setenv("MFC_IMF_MERGE", merge)
@@ -101,7 +102,7 @@ def test_merged_two_pass_schedule_equals_the_plain_one(monkeypatch):
                                                                                for k, v in aux.items()})
         assert bool(aux.get("tangent_rows_last", False)) == (merge == "1")
     (l1, g1, a1), (l0, g0, a0) = outs["1"], outs["0"]
-    assert a1["n_tan"] == a0["n_tan"] == 4
+    assert a1["n_tan"] == a0["n_tan"] == int((t != r).sum().item()) and 0 < a1["n_tan"] < 7
     assert abs(l1 - l0) < 1e-6 * max(1.0, abs(l0))
     for k in ("u", "dudt", "v", "per_example"):
         assert _rel(a1[k], a0[k].double().cpu()) < 2e-5, k

@@ -1,12 +1,28 @@
 #!/bin/bash
 # Effective shader clock per kernel = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration (MI355X_MICROARCH.md, DVFS section).
-# usage (GPU box): tools/probe_clock.sh <out dir> python3 tools/bench_cnx.py 64
+# usage (GPU box, from the repo root): tools/probe_clock.sh <out dir> tools/bench_cnx.py 64
+# The profiled program is always `python3 <absolute script path> <args>`: under --pmc only the program itself may follow
+# `--` (no env / bash -c / launcher hop), and the script path is resolved against the repo root BEFORE the cd to /tmp.
 OUT=$1; shift
+SCRIPT=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+case "$SCRIPT" in
+  /*) ;;
+  *) SCRIPT="$R/$SCRIPT" ;;
+esac
+case "$SCRIPT" in
+  *.py) ;;
+  *) echo "usage: tools/probe_clock.sh <out dir> <python script> [args]   (got: $SCRIPT)" >&2; exit 2 ;;
+esac
+[ -f "$SCRIPT" ] || { echo "no such script: $SCRIPT" >&2; exit 2; }
+case "$OUT" in
+  /*) ;;
+  *) OUT="$R/$OUT" ;;
+esac
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d "$OUT" --output-format csv -- "$@" > "$OUT/run.log" 2>&1 || exit 1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d "$OUT" --output-format csv -- python3 "$SCRIPT" "$@" > "$OUT/run.log" 2>&1 || exit 1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
