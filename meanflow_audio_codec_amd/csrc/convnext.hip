@@ -1483,21 +1483,30 @@ cnx_bwd_conv_kernel(BwdArgs a) {
 
 // ---------------------------------------------------------------------------
 // "From n1" kernels.  The statistics pass can keep n1 = LN(conv3x3(FiLM(h1))) -- the 16-channel map the expansion
-// consumes -- and its 1/sigma (mfc_cnx_stats_save).  Everything downstream of n1 is PER PIXEL (1x1 convs, GELU, GRN,
-// layer scale, residual), so the apply pass and the two reverse kernels that used to repeat the conv and the
-// LayerNorm become plain streaming kernels: no halo, no LDS tiles, no DMA, no workgroup barrier in the loop.  A wave
-// owns 16 consecutive pixels of the flattened image per step; the MFMA B-operand fragment of lane (q, m) -- channels
-// 4q..4q+3 of pixel m -- is exactly the 8 (bf16) / 16 (fp32) bytes at that pixel, so the fragments come straight from
-// buffer loads (512 / 1024 contiguous bytes per wave instruction), prefetched one step ahead.
-// Unit of work: one "step" = 64 consecutive pixels of one image (16 per wave); an image has spi = ceil(s*s / 64)
-// steps (the last one partly out of bounds: those lanes load zeros and store nowhere); a workgroup walks a
-// contiguous range of steps.  Per-row (r) sums are flushed when the range crosses into the next image, exactly like
-// the tile kernels (same record layout, same fixed-order reduce kernels).
+// consumes -- its 1/sigma and (tangent rows) its tangent (mfc_cnx_stats_save).  Everything downstream of n1 is PER
+// PIXEL (1x1 convs, GELU, GRN, layer scale, residual), so the apply pass and the two reverse kernels that used to
+// repeat the conv and the LayerNorm become plain streaming kernels: no halo, no tiles, no workgroup barrier in the loop.
+//
+// Work unit: one "step" = 128 consecutive pixels of one image's flattened [s*s, 16] map, 32 per wave = two MFMA
+// column groups of 16 pixels.  An image has spi = ceil(s*s / 128) steps (the last one partly out of bounds: those
+// pixels load zeros and store nowhere); a workgroup walks a contiguous range of steps; per-row (r) sums are flushed when
+// the range crosses into the next image, exactly like the tile kernels (same records, same fixed-order reduce kernels).
+//
+// HBM access is 16 bytes per lane in both directions (PixIO): a wave's 32-pixel span of a tensor is one contiguous
+// 1 KB (bf16) / 2 KB (fp32) piece, fetched by LDS-DMA (global_load_lds_dwordx4, double-buffered, requested one step
+// ahead: no staging registers, no VALU on full spans -- the address is a scalar base + the lane's constant offset) into
+// a wave-private LDS buffer, from which the MFMA B-operand fragments (channels 4q..4q+3 of pixel m: 8 / 16 bytes) are
+// read conflict-free; results go the other way -- fragments into a wave-private LDS image, 16-byte chunks out of it
+// into buffer stores.  (The first version loaded the 8-byte bf16 fragments straight from global memory: 512 bytes per
+// wave instruction reached 4.7 TB/s in the apply kernel; see DESIGN.md for the measured difference.)
 // ---------------------------------------------------------------------------
+constexpr int PIX_STEP = 128, PIX_WAVE = PIX_STEP / NWAVES;     // pixels per workgroup / per wave and step
+static_assert(PIX_WAVE == 32, "two 16-pixel MFMA column groups per wave");
+
 inline Geo make_pix_geo(int64_t R, int s, int64_t maxBlocks, int64_t& grid) {
     Geo g;
     g.R = R; g.s = s; g.tilesX = 0; g.tilesY = 0;
-    g.tilesPerImg = ((int64_t)s * s + 63) / 64;          // steps per image
+    g.tilesPerImg = ((int64_t)s * s + PIX_STEP - 1) / PIX_STEP;          // steps per image
     g.total = R * g.tilesPerImg;
     grid = g.total < maxBlocks ? g.total : maxBlocks;
     g.chunk = (g.total + grid - 1) / grid;
@@ -1517,6 +1526,69 @@ struct PixArgs {
     float* ws;
 };
 
+// Wave-private streaming I/O of NIN input and NOUT output tensors ([R, s*s, 16] maps of T), one 32-pixel span per step.
+template <typename T, int NIN, int NOUT> struct PixIO {
+    static constexpr int TB = PIX_WAVE * 16 * (int)sizeof(T);   // bytes of one tensor's span: 1 KB (bf16) / 2 KB (fp32)
+    static constexpr int NI = TB / 1024;                         // DMA / store instructions per tensor and step
+    static constexpr int S_VMEM = NOUT * NI;                     // stores issued after a request (vmcnt note)
+    static constexpr int WAVE_BYTES = (2 * NIN + NOUT) * TB;
+    typedef typename Frag<T>::type frag_t;
+    unsigned char* in;       // [2][NIN][TB]
+    unsigned char* out;      // [NOUT][TB]
+    uint32_t in_addr;        // LDS byte address of `in` (M0 of the DMA)
+    int64_t npix, img_bytes;
+    uint32_t lane16;         // this lane's byte offset inside a 1 KB DMA piece
+
+    __device__ inline void init(unsigned char* wave_base, int64_t npix_, int lane) {
+        in = wave_base; out = wave_base + 2 * NIN * TB;
+        in_addr = (uint32_t)(uintptr_t)(lvoid_t*)wave_base;
+        npix = npix_; img_bytes = npix_ * 16 * (int64_t)sizeof(T);
+        lane16 = (uint32_t)lane * 16u;
+    }
+    // request the spans [px0, px0 + 32) of image r of every input tensor into buffer b
+    __device__ inline void request(int b, const void* const (&base)[NIN], int64_t r, int64_t px0) const {
+        const bool full = px0 + PIX_WAVE <= npix;        // wave-uniform
+        const int64_t span = r * img_bytes + px0 * 16 * (int64_t)sizeof(T);
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            const char* sb = reinterpret_cast<const char*>(base[k]) + span;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const uint32_t lds_addr = in_addr + (uint32_t)(((b * NIN + k) * NI + i) * 1024);
+                const uint32_t off = lane16 + (uint32_t)(i * 1024);
+                if (full) {
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                                 :: "v"(off), "s"(sb), "s"(lds_addr) : "memory", "m0");
+                } else {
+                    const bool in_img = px0 + (int64_t)(off / (16 * sizeof(T))) < npix;
+                    const void* gp = in_img ? static_cast<const void*>(sb + off) : static_cast<const void*>(&g_zero16);
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                                 :: "v"(gp), "s"(lds_addr) : "memory", "m0");
+                }
+            }
+        }
+    }
+    // fragment (channels 4q .. 4q+3 of pixel 16 sub + m) of input tensor k in buffer b
+    __device__ inline frag_t frag(int b, int k, int sub, int q, int m) const {
+        return *reinterpret_cast<const frag_t*>(in + (b * NIN + k) * TB + ((sub * 16 + m) * 16 + 4 * q) * (int)sizeof(T));
+    }
+    __device__ inline void put(int k, int sub, int q, int m, const float v[4]) const {
+        frag_t f;
+        make_frag(f, v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<frag_t*>(out + k * TB + ((sub * 16 + m) * 16 + 4 * q) * (int)sizeof(T)) = f;
+    }
+    // store output tensor k's span (pixels past the end of the image are steered out of bounds)
+    __device__ inline void store(int k, __amdgpu_buffer_rsrc_t rs, int64_t px0) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const uint32_t off = lane16 + (uint32_t)(i * 1024);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(out + k * TB + off);
+            const bool in_img = px0 + (int64_t)(off / (16 * sizeof(T))) < npix;
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, in_img ? (uint32_t)(px0 * 16 * sizeof(T)) + off : BUF_OOB, 0, 0);
+        }
+    }
+};
+
 // expansion + GELU of one wave row from its n1 fragment (the tail of chain_row)
 template <typename T, bool WG>
 __device__ inline void expand_gelu(const FwdW<T>& w, const typename Frag<T>::type& n1f, f32x4 g[2], f32x4 gp[2]) {
@@ -1533,9 +1605,11 @@ __device__ inline void expand_gelu(const FwdW<T>& w, const typename Frag<T>::typ
 // and (JVP) its tangent from the kept tangent of n1 -- the same expressions, in the same order, as the tile kernel
 // evaluates after its LayerNorm: results are bit-identical.
 template <typename T, bool JVP>
-__global__ void __launch_bounds__(NT, sizeof(T) == 2 ? (JVP ? 3 : 4) : 1)
+__global__ void __launch_bounds__(NT, sizeof(T) == 2 ? 4 : 1)
 cnx_apply_n1_kernel(PixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Frag<T>::type frag_t;
+    typedef PixIO<T, JVP ? 4 : 2, JVP ? 2 : 1> IO;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, m = lane & 15;
@@ -1543,6 +1617,11 @@ cnx_apply_n1_kernel(PixArgs a) {
     w.load(a.p, q, m);
     const int s = a.geo.s;
     const int64_t npix = (int64_t)s * s, img = npix * 16, spi = a.geo.tilesPerImg;
+    IO io;
+    io.init(smem + (size_t)wave * IO::WAVE_BYTES, npix, lane);
+    const void* ins[JVP ? 4 : 2];
+    ins[0] = a.n1; ins[1] = a.h1;
+    if constexpr (JVP) { ins[2] = a.n1d; ins[3] = a.h1d; }
     const int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
     const int64_t t1 = t0 + a.geo.chunk < a.geo.total ? t0 + a.geo.chunk : a.geo.total;
     if (t0 >= t1) return;
@@ -1552,27 +1631,10 @@ cnx_apply_n1_kernel(PixArgs a) {
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 gq[2] = {z4, z4}, qdv[2] = {z4, z4}, sc14 = z4, sh4 = z4, scd4 = z4, shd4 = z4;
     __amdgpu_buffer_rsrc_t rs_o = make_rsrc(nullptr, 0), rs_od = make_rsrc(nullptr, 0);
-    auto off_of = [&](int64_t jj) -> uint32_t {
-        const int64_t px = (jj * 4 + wave) * 16 + m;
-        return px < npix ? (uint32_t)((px * 16 + 4 * q) * sizeof(T)) : BUF_OOB;
-    };
-    struct Ops { frag_t n, h, nd, hd; };
-    auto fetch = [&](int64_t rr, int64_t jj, Ops& o) {
-        const uint32_t off = off_of(jj);
-        const uint32_t bytes = (uint32_t)(img * sizeof(T));
-        o.n = buf_ld_frag(make_rsrc((const T*)a.n1 + rr * img, bytes), off, (const T*)nullptr);
-        o.h = buf_ld_frag(make_rsrc((const T*)a.h1 + rr * img, bytes), off, (const T*)nullptr);
-        if constexpr (JVP) {
-            o.nd = buf_ld_frag(make_rsrc((const T*)a.n1d + rr * img, bytes), off, (const T*)nullptr);
-            o.hd = buf_ld_frag(make_rsrc((const T*)a.h1d + rr * img, bytes), off, (const T*)nullptr);
-        }
-    };
-    Ops nx;
-    fetch(r, j, nx);
+    io.request(0, ins, r, j * PIX_STEP + wave * PIX_WAVE);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int64_t t = t0; t < t1; ++t) {
-        const Ops cur = nx;
-        land(cur.n); land(cur.h);
-        if constexpr (JVP) { land(cur.nd); land(cur.hd); }
+        const int cur = (int)((t - t0) & 1);
         const int64_t rt = r, jt = j;
         if (++j == spi) { j = 0; ++r; }
         if (rt != rcur) {
@@ -1598,50 +1660,63 @@ cnx_apply_n1_kernel(PixArgs a) {
             if constexpr (JVP) rs_od = make_rsrc((const T*)a.od + rt * img, (uint32_t)(img * sizeof(T)));
         }
         __builtin_amdgcn_sched_barrier(0);
-        // next step's operands (past the end: this step again -- the instruction count stays fixed)
-        if (t + 1 < t1) fetch(r, j, nx); else fetch(rt, jt, nx);
+        // next step's spans (past the end: this step again into the other buffer -- the instruction count stays fixed)
+        if (t + 1 < t1) io.request(cur ^ 1, ins, r, j * PIX_STEP + wave * PIX_WAVE);
+        else io.request(cur ^ 1, ins, rt, jt * PIX_STEP + wave * PIX_WAVE);
         __builtin_amdgcn_sched_barrier(0);
-        f32x4 g[2], gp[2], gd[2];
-        expand_gelu<T, JVP>(w, cur.n, g, gp);
-        if constexpr (JVP) {
+        const int64_t px0 = jt * PIX_STEP + wave * PIX_WAVE;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const frag_t n1f = io.frag(cur, 0, sub, q, m), h1f = io.frag(cur, 1, sub, q, m);
+            f32x4 g[2], gp[2], gd[2];
+            expand_gelu<T, JVP>(w, n1f, g, gp);
+            if constexpr (JVP) {
+                const frag_t n1df = io.frag(cur, 2, sub, q, m);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    f32x4 ed = z4;
+                    mma16(ed, w.we[jj], n1df);
+                    gd[jj] = ed * gp[jj];
+                }
+            }
+            f32x4 p1 = ld_f32x4(w.bp), p1d = z4;
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
-                f32x4 ed = z4;
-                mma16(ed, w.we[jj], cur.nd);
-                gd[jj] = ed * gp[jj];
+                frag_t yf;
+                const f32x4 yv = fma4(g[jj], gq[jj], ld_f32x4(w.bet[jj]));
+                make_frag(yf, yv[0], yv[1], yv[2], yv[3]);
+                mma16(p1, w.wp[jj], yf);
+                if constexpr (JVP) {
+                    frag_t ydf;
+                    const f32x4 ydv = fma4(gd[jj], gq[jj], g[jj] * qdv[jj]);
+                    make_frag(ydf, ydv[0], ydv[1], ydv[2], ydv[3]);
+                    mma16(p1d, w.wp[jj], ydf);
+                }
             }
-        }
-        f32x4 p1 = ld_f32x4(w.bp), p1d = z4;
+            float hv[4], ov[4];
+            unfrag(h1f, hv);
+            const f32x4 nv = ld_f32x4(hv), ls4 = ld_f32x4(w.ls);
+            const f32x4 o4 = fma4(p1, ls4, fma4(sc14, nv, sh4));
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            frag_t yf;
-            const f32x4 yv = fma4(g[jj], gq[jj], ld_f32x4(w.bet[jj]));
-            make_frag(yf, yv[0], yv[1], yv[2], yv[3]);
-            mma16(p1, w.wp[jj], yf);
+            for (int i = 0; i < 4; ++i) ov[i] = o4[i];
+            io.put(0, sub, q, m, ov);
             if constexpr (JVP) {
-                frag_t ydf;
-                const f32x4 ydv = fma4(gd[jj], gq[jj], g[jj] * qdv[jj]);
-                make_frag(ydf, ydv[0], ydv[1], ydv[2], ydv[3]);
-                mma16(p1d, w.wp[jj], ydf);
+                float hdv[4];
+                unfrag(io.frag(cur, 3, sub, q, m), hdv);
+                const f32x4 od4 = fma4(p1d, ls4, fma4(sc14, ld_f32x4(hdv), fma4(scd4, nv, shd4)));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = od4[i];
+                io.put(1, sub, q, m, ov);
             }
         }
-        float hv[4], ov[4];
-        unfrag(cur.h, hv);
-        const f32x4 nv = ld_f32x4(hv), ls4 = ld_f32x4(w.ls);
-        const f32x4 o4 = fma4(p1, ls4, fma4(sc14, nv, sh4));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ov[i] = o4[i];
-        const uint32_t goff = off_of(jt);
-        buf_st4(rs_o, goff, ov, (const T*)nullptr);
-        if constexpr (JVP) {
-            float hdv[4];
-            unfrag(cur.hd, hdv);
-            const f32x4 od4 = fma4(p1d, ls4, fma4(sc14, ld_f32x4(hdv), fma4(scd4, nv, shd4)));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ov[i] = od4[i];
-            buf_st4(rs_od, goff, ov, (const T*)nullptr);
-        }
+        io.store(0, rs_o, px0);
+        if constexpr (JVP) io.store(1, rs_od, px0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IO::S_VMEM) : "memory");   // this wave's next spans have landed
     }
+}
+template <typename T> inline size_t lds_apply_n1_bytes(bool jvp) {
+    return (size_t)NWAVES * (jvp ? PixIO<T, 4, 2>::WAVE_BYTES : PixIO<T, 2, 1>::WAVE_BYTES);
 }
 
 // MODE 0 / MODE 1 of cnx_bwd_kernel from n1 (and, MODE 1, its 1/sigma rho1).
@@ -1656,12 +1731,14 @@ __global__ void __launch_bounds__(NT, sizeof(T) == 2 ? (MODE == 0 ? 4 : 3) : 1)
 cnx_bwd_n1_kernel(PixArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Frag<T>::type frag_t;
+    typedef PixIO<T, 2, MODE == 1 ? 1 : 0> IO;       // in: n1, dout; out: dc1 (MODE 1)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, m = lane & 15;
-    // LDS: per wave 2 x [6][16][CS] transpose scratch (MODE 1: double-buffered), then the cross-wave flush scratch
-    T* wsT = reinterpret_cast<T*>(smem) + (size_t)wave * 2 * WS_TILES * 16 * CS;
-    float* red = reinterpret_cast<float*>(smem + (MODE == 1 ? (((size_t)NWAVES * 2 * WS_TILES * 16 * CS * sizeof(T)) + 15) / 16 * 16 : 0));
+    // LDS: the waves' I/O buffers, the cross-wave flush scratch, then (MODE 1) per wave a [6][16][CS] transpose scratch
+    constexpr size_t IO_BYTES = (size_t)NWAVES * IO::WAVE_BYTES;
+    float* red = reinterpret_cast<float*>(smem + IO_BYTES);
+    T* wsT = reinterpret_cast<T*>(smem + IO_BYTES + (size_t)REC_MAIN * sizeof(float)) + (size_t)wave * WS_TILES * 16 * CS;
     FwdW<T> w;
     w.load(a.p, q, m);
     const T* pw = (const T*)a.p.con_w;  // [32][16]: dy[e] = sum_c Wp[e][c] ls[c] dout[c]
@@ -1679,6 +1756,9 @@ cnx_bwd_n1_kernel(PixArgs a) {
     make_frag(ones, 1.0f, 1.0f, 1.0f, 1.0f);
     const int s = a.geo.s;
     const int64_t npix = (int64_t)s * s, img = npix * 16, spi = a.geo.tilesPerImg;
+    IO io;
+    io.init(smem + (size_t)wave * IO::WAVE_BYTES, npix, lane);
+    const void* ins[2] = {a.n1, a.dout};
     const int64_t t0 = (int64_t)blockIdx.x * a.geo.chunk;
     const int64_t t1 = t0 + a.geo.chunk < a.geo.total ? t0 + a.geo.chunk : a.geo.total;
     int64_t r = t0 < t1 ? t0 / spi : 0;
@@ -1712,21 +1792,16 @@ cnx_bwd_n1_kernel(PixArgs a) {
             __syncthreads();
         }
     };
-    auto off_of = [&](int64_t jj) -> uint32_t {
-        const int64_t px = (jj * 4 + wave) * 16 + m;
-        return px < npix ? (uint32_t)((px * 16 + 4 * q) * sizeof(T)) : BUF_OOB;
-    };
-    auto roff_of = [&](int64_t jj) -> uint32_t {
-        const int64_t px = (jj * 4 + wave) * 16 + m;
-        return px < npix ? (uint32_t)(px * 4) : BUF_OOB;
-    };
-    auto fetch = [&](int64_t rr, int64_t jj, frag_t& n, frag_t& d, float& rho) {
-        const uint32_t off = off_of(jj);
-        n = buf_ld_frag(make_rsrc((const T*)a.n1 + rr * img, (uint32_t)(img * sizeof(T))), off, (const T*)nullptr);
-        d = buf_ld_frag(make_rsrc((const T*)a.dout + rr * img, (uint32_t)(img * sizeof(T))), off, (const T*)nullptr);
-        if constexpr (MODE == 1)
-            rho = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                      make_rsrc(a.rho1 + rr * npix, (uint32_t)(npix * sizeof(float))), roff_of(jj), 0, 0));
+    // 1/sigma of this lane's pixel in each of the two column groups (MODE 1): plain loads, one step ahead
+    auto fetch_rho = [&](int64_t rr, int64_t jj, float rho[2]) {
+        if constexpr (MODE == 1) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.rho1 + rr * npix, (uint32_t)(npix * sizeof(float)));
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int64_t px = jj * PIX_STEP + wave * PIX_WAVE + sub * 16 + m;
+                rho[sub] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, px < npix ? (uint32_t)(px * 4) : BUF_OOB, 0, 0));
+            }
+        }
     };
     auto wgrad_from = [&](const T* wb) {
         const frag_t tdo = pix_k_frag<T>(wb + 2 * 16 * CS, q, m);
@@ -1741,14 +1816,16 @@ cnx_bwd_n1_kernel(PixArgs a) {
         mma16(aS, ones, tdo);           // every row: sum_p dout[p][c]
         lds_fence();
     };
-    frag_t nn, dn;
-    float rn = 0.f;
-    if (t0 < t1) fetch(r, j, nn, dn, rn);
+    float rn[2] = {0.f, 0.f};
+    if (t0 < t1) {
+        fetch_rho(r, j, rn);
+        io.request(0, ins, r, j * PIX_STEP + wave * PIX_WAVE);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int64_t t = t0; t < t1; ++t) {
-        const frag_t n1f = nn, dof = dn;                    // dout: zero outside the image
-        const float rho1 = rn;
-        land(n1f); land(dof);
-        if constexpr (MODE == 1) land(rho1);
+        const int cur = (int)((t - t0) & 1);
+        const float rho1[2] = {rn[0], rn[1]};
+        if constexpr (MODE == 1) { land(rho1[0]); land(rho1[1]); }
         const int64_t rt = r, jt = j;
         if (++j == spi) { j = 0; ++r; }
         if (rt != rcur) {
@@ -1766,68 +1843,75 @@ cnx_bwd_n1_kernel(PixArgs a) {
             if constexpr (MODE == 1) rs_dc = make_rsrc((const T*)a.dc1 + rt * img, (uint32_t)(img * sizeof(T)));
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < t1) fetch(r, j, nn, dn, rn); else fetch(rt, jt, nn, dn, rn);
-        __builtin_amdgcn_sched_barrier(0);
-        const uint32_t goff = off_of(jt);
-        f32x4 g[2], gp[2];
-        expand_gelu<T, MODE == 1>(w, n1f, g, gp);
-        f32x4 dy[2];
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            dy[jj] = z4;
-            mma16(dy[jj], wpT[jj], dof);       // dy^T = (Wp diag(ls)) dout^T
-        }
-        if constexpr (MODE == 0) {
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) dqp[jj] = fma4(dy[jj], g[jj], dqp[jj]);
+        // next step: the 1/sigma loads first (older than the DMA: the counted wait below then covers them too), then the
+        // spans (past the end: this step again into the other buffer -- the instruction count stays fixed)
+        if (t + 1 < t1) {
+            fetch_rho(r, j, rn);
+            io.request(cur ^ 1, ins, r, j * PIX_STEP + wave * PIX_WAVE);
         } else {
-            // the pixels past the end of the image (last step of an image only) must not reach d exp_b: g != 0 there
-            frag_t yf[2], def[2];
-            f32x4 de[2];
+            fetch_rho(rt, jt, rn);
+            io.request(cur ^ 1, ins, rt, jt * PIX_STEP + wave * PIX_WAVE);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int64_t px0 = jt * PIX_STEP + wave * PIX_WAVE;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const frag_t n1f = io.frag(cur, 0, sub, q, m), dof = io.frag(cur, 1, sub, q, m);    // dout: zero outside the image
+            f32x4 g[2], gp[2];
+            expand_gelu<T, MODE == 1>(w, n1f, g, gp);
+            f32x4 dy[2];
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
-                const f32x4 yv = fma4(g[jj], gq[jj], bet4[jj]);
-                make_frag(yf[jj], yv[0], yv[1], yv[2], yv[3]);
-                de[jj] = fma4(dy[jj], gq[jj], g[jj] * kg[jj]) * gp[jj];
-                dbe[jj] = dbe[jj] + de[jj];
-                make_frag(def[jj], de[0 + jj][0], de[jj][1], de[jj][2], de[jj][3]);
+                dy[jj] = z4;
+                mma16(dy[jj], wpT[jj], dof);       // dy^T = (Wp diag(ls)) dout^T
             }
-            // The pixels past the end of the image (last step of an image only: n1 = dout = 0 there, but g(be) != 0) must
-            // not reach d exp_b -- everything else they touch is multiplied by a zero or never stored.  Taken back here,
-            // in a branch the other 6000 steps of the image skip.
-            if (jt == spi - 1) [[unlikely]] {
-                if (goff == BUF_OOB) { dbe[0] = dbe[0] - de[0]; dbe[1] = dbe[1] - de[1]; }
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) dqp[jj] = fma4(dy[jj], g[jj], dqp[jj]);
+            } else {
+                frag_t yf[2], def[2];
+                f32x4 de[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const f32x4 yv = fma4(g[jj], gq[jj], bet4[jj]);
+                    make_frag(yf[jj], yv[0], yv[1], yv[2], yv[3]);
+                    de[jj] = fma4(dy[jj], gq[jj], g[jj] * kg[jj]) * gp[jj];
+                    dbe[jj] = dbe[jj] + de[jj];
+                    make_frag(def[jj], de[jj][0], de[jj][1], de[jj][2], de[jj][3]);
+                }
+                // The pixels past the end of the image (last step of an image only: n1 = dout = 0 there, but g(be) != 0)
+                // must not reach d exp_b -- everything else they touch is multiplied by a zero or never stored.  Taken
+                // back here, in a branch the other steps of the image skip.
+                if (jt == spi - 1) [[unlikely]] {
+                    if (px0 + sub * 16 + m >= npix) { dbe[0] = dbe[0] - de[0]; dbe[1] = dbe[1] - de[1]; }
+                }
+                f32x4 dn1 = z4;
+                mma_pair(dn1, weT[0], weT[1], def[0], def[1]);      // dn1^T = We de^T
+                // LayerNorm backward: dc = rho (dn - mean(dn) - n mean(dn n))
+                float n1[4];
+                unfrag(n1f, n1);
+                const f32x4 n4 = ld_f32x4(n1);
+                float m1 = (dn1[0] + dn1[1]) + (dn1[2] + dn1[3]);
+                float m2 = dn1[0] * n1[0] + dn1[1] * n1[1] + dn1[2] * n1[2] + dn1[3] * n1[3];
+                red_q2(m1, m2);
+                const f32x4 dc4 = (fma4(n4, splat4(m2 * (-1.0f / 16.0f)), dn1) - splat4(m1 * (1.0f / 16.0f))) * splat4(rho1[sub]);
+                float dc[4] = {dc4[0], dc4[1], dc4[2], dc4[3]};
+                io.put(0, sub, q, m, dc);
+                // weight gradients contract over the 16 pixels of the column group: one batched transpose (pixel-on-lane
+                // -> pixel-as-k) through the wave's LDS scratch (a wave's LDS operations execute in order)
+                *reinterpret_cast<frag_t*>(wsT + (0 * 16 + m) * CS + 4 * q) = yf[0];
+                *reinterpret_cast<frag_t*>(wsT + (1 * 16 + m) * CS + 4 * q) = yf[1];
+                *reinterpret_cast<frag_t*>(wsT + (2 * 16 + m) * CS + 4 * q) = dof;
+                *reinterpret_cast<frag_t*>(wsT + (3 * 16 + m) * CS + 4 * q) = n1f;     // (pixels outside the image meet de = 0)
+                *reinterpret_cast<frag_t*>(wsT + (4 * 16 + m) * CS + 4 * q) = def[0];
+                *reinterpret_cast<frag_t*>(wsT + (5 * 16 + m) * CS + 4 * q) = def[1];
+                lds_fence();
+                wgrad_from(wsT);
             }
-            f32x4 dn1 = z4;
-            mma_pair(dn1, weT[0], weT[1], def[0], def[1]);      // dn1^T = We de^T
-            // LayerNorm backward: dc = rho (dn - mean(dn) - n mean(dn n))
-            float n1[4];
-            unfrag(n1f, n1);
-            const f32x4 n4 = ld_f32x4(n1);
-            float m1 = (dn1[0] + dn1[1]) + (dn1[2] + dn1[3]);
-            float m2 = dn1[0] * n1[0] + dn1[1] * n1[1] + dn1[2] * n1[2] + dn1[3] * n1[3];
-            red_q2(m1, m2);
-            const f32x4 dc4 = (fma4(n4, splat4(m2 * (-1.0f / 16.0f)), dn1) - splat4(m1 * (1.0f / 16.0f))) * splat4(rho1);
-            float dc[4] = {dc4[0], dc4[1], dc4[2], dc4[3]};
-            buf_st4(rs_dc, goff, dc, (const T*)nullptr);
-            // Weight gradients contract over the 16 pixels of the wave row: one batched transpose (pixel-on-lane ->
-            // pixel-as-k) through the wave's LDS scratch.  The scratch is double-buffered and the transposed reads run ONE
-            // STEP BEHIND the writes: the tiles read here were written a whole step ago, so neither the LDS turnaround nor
-            // the accumulating MFMAs sit on this step's dependency chain (a wave's LDS operations execute in order).
-            T* wcur = wsT + ((t - t0) & 1) * (WS_TILES * 16 * CS);
-            const T* wprev = wsT + (((t - t0) & 1) ^ 1) * (WS_TILES * 16 * CS);
-            if (t > t0) wgrad_from(wprev);
-            *reinterpret_cast<frag_t*>(wcur + (0 * 16 + m) * CS + 4 * q) = yf[0];
-            *reinterpret_cast<frag_t*>(wcur + (1 * 16 + m) * CS + 4 * q) = yf[1];
-            *reinterpret_cast<frag_t*>(wcur + (2 * 16 + m) * CS + 4 * q) = dof;
-            *reinterpret_cast<frag_t*>(wcur + (3 * 16 + m) * CS + 4 * q) = n1f;     // (rows outside the image meet de = 0)
-            *reinterpret_cast<frag_t*>(wcur + (4 * 16 + m) * CS + 4 * q) = def[0];
-            *reinterpret_cast<frag_t*>(wcur + (5 * 16 + m) * CS + 4 * q) = def[1];
-            lds_fence();
         }
-    }
-    if constexpr (MODE == 1) {
-        if (t0 < t1) wgrad_from(wsT + ((t1 - 1 - t0) & 1) * (WS_TILES * 16 * CS));     // the last step's tiles
+        if constexpr (MODE == 1) io.store(0, rs_dc, px0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IO::S_VMEM) : "memory");   // this wave's next spans (and 1/sigma) have landed
     }
     if (rcur >= 0) flush_row();
     if constexpr (MODE == 0) {
@@ -1879,8 +1963,9 @@ cnx_bwd_n1_kernel(PixArgs a) {
     }
 }
 template <typename T> inline size_t lds_bwd_n1_bytes(int mode) {
-    if (mode == 0) return (size_t)NWAVES * REC_DQ * sizeof(float);
-    return (((size_t)NWAVES * 2 * WS_TILES * 16 * CS * sizeof(T)) + 15) / 16 * 16 + (size_t)REC_MAIN * sizeof(float);
+    const size_t io = (size_t)NWAVES * (mode == 1 ? PixIO<T, 2, 1>::WAVE_BYTES : PixIO<T, 2, 0>::WAVE_BYTES);
+    const size_t scratch = (size_t)REC_MAIN * sizeof(float);      // (MODE 0 uses its first NWAVES * REC_DQ floats)
+    return io + scratch + (mode == 1 ? (size_t)NWAVES * WS_TILES * 16 * CS * sizeof(T) : 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -2052,7 +2137,7 @@ inline bool params_ok(const mfc_cnx_params* p) {
 // tile became compact and single-buffered, one round of 768 (-7 % against two per CU).  MFC_CNX_MAX_BLOCKS / mfc_cnx_max_blocks override all.
 enum CnxKind { K_STATS = 0, K_APPLY, K_STATS_JVP, K_APPLY_JVP, K_BWD_STATS, K_BWD_MAIN, K_BWD_CONV, K_APPLY_N1, K_BWD_STATS_N1,
                K_BWD_MAIN_N1, K_APPLY_JVP_N1, K_NKIND };
-static const int64_t DEFAULT_BLOCKS[K_NKIND] = {3072, 3072, 2304, 512, 3072, 512, 768, 3072, 3072, 2304, 2304};
+static const int64_t DEFAULT_BLOCKS[K_NKIND] = {3072, 3072, 2304, 512, 3072, 512, 768, 3072, 3072, 2304, 3072};
 inline bool kind_is_pix(int k) { return k >= K_APPLY_N1; }
 static int64_t MAX_BLOCKS = getenv("MFC_CNX_MAX_BLOCKS") ? atoll(getenv("MFC_CNX_MAX_BLOCKS")) : 0;   // 0: per-kernel defaults
 inline int64_t max_blocks(CnxKind k) { return MAX_BLOCKS > 0 ? MAX_BLOCKS : DEFAULT_BLOCKS[k]; }
@@ -2159,10 +2244,10 @@ extern "C" int mfc_cnx_apply_n1(int dtype, int64_t R, int s, const void* n1, con
     a.p = to_dev(p); a.q = q; a.qd = qdot; a.o = o; a.od = odot;
     hipStream_t st = (hipStream_t)stream;
     if (jvp)
-        return dtype == MFC_F32 ? launch_k(cnx_apply_n1_kernel<float, true>, grid, 0, st, a)
-                                : launch_k(cnx_apply_n1_kernel<u16, true>, grid, 0, st, a);
-    return dtype == MFC_F32 ? launch_k(cnx_apply_n1_kernel<float, false>, grid, 0, st, a)
-                            : launch_k(cnx_apply_n1_kernel<u16, false>, grid, 0, st, a);
+        return dtype == MFC_F32 ? launch_k(cnx_apply_n1_kernel<float, true>, grid, lds_apply_n1_bytes<float>(true), st, a)
+                                : launch_k(cnx_apply_n1_kernel<u16, true>, grid, lds_apply_n1_bytes<u16>(true), st, a);
+    return dtype == MFC_F32 ? launch_k(cnx_apply_n1_kernel<float, false>, grid, lds_apply_n1_bytes<float>(false), st, a)
+                            : launch_k(cnx_apply_n1_kernel<u16, false>, grid, lds_apply_n1_bytes<u16>(false), st, a);
 }
 
 extern "C" int mfc_cnx_bwd_stats_n1(int dtype, int64_t R, int s, const void* n1, const mfc_cnx_params* p, const float* q,
