@@ -1527,20 +1527,26 @@ struct PixArgs {
 };
 
 // Wave-private streaming I/O of NIN input and NOUT output tensors ([R, s*s, 16] maps of T), one 32-pixel span per step.
-template <typename T, int NIN, int NOUT> struct PixIO {
+// NBUF input buffers: a step's spans are requested NBUF - 1 steps ahead (the memory-bound kernels take 3: one step of a
+// wave is only 2-4 KB, and with five workgroups per CU a single step in flight per wave covers ~3 us of latency at
+// 3 TB/s, not at 6).
+template <typename T, int NIN, int NOUT, int NBUF = 2> struct PixIO {
     static constexpr int TB = PIX_WAVE * 16 * (int)sizeof(T);   // bytes of one tensor's span: 1 KB (bf16) / 2 KB (fp32)
     static constexpr int NI = TB / 1024;                         // DMA / store instructions per tensor and step
-    static constexpr int S_VMEM = NOUT * NI;                     // stores issued after a request (vmcnt note)
-    static constexpr int WAVE_BYTES = (2 * NIN + NOUT) * TB;
+    // VMEM instructions younger than the request of step t + 1 when step t ends (vmcnt note): that request was issued
+    // NBUF - 1 steps ago; since then the stores of NBUF - 1 steps and the requests of NBUF - 2 later steps
+    static constexpr int S_VMEM = (NBUF - 1) * NOUT * NI + (NBUF - 2) * NIN * NI;
+    static constexpr int WAVE_BYTES = (NBUF * NIN + NOUT) * TB;
+    static constexpr int DEPTH = NBUF - 1;
     typedef typename Frag<T>::type frag_t;
-    unsigned char* in;       // [2][NIN][TB]
+    unsigned char* in;       // [NBUF][NIN][TB]
     unsigned char* out;      // [NOUT][TB]
     uint32_t in_addr;        // LDS byte address of `in` (M0 of the DMA)
     int64_t npix, img_bytes;
     uint32_t lane16;         // this lane's byte offset inside a 1 KB DMA piece
 
     __device__ inline void init(unsigned char* wave_base, int64_t npix_, int lane) {
-        in = wave_base; out = wave_base + 2 * NIN * TB;
+        in = wave_base; out = wave_base + NBUF * NIN * TB;
         in_addr = (uint32_t)(uintptr_t)(lvoid_t*)wave_base;
         npix = npix_; img_bytes = npix_ * 16 * (int64_t)sizeof(T);
         lane16 = (uint32_t)lane * 16u;
@@ -1589,6 +1595,12 @@ template <typename T, int NIN, int NOUT> struct PixIO {
     }
 };
 
+struct PixPos { int64_t r, j; };
+__device__ inline PixPos pix_next(PixPos p, int64_t spi) {
+    if (++p.j == spi) { p.j = 0; ++p.r; }
+    return p;
+}
+
 // expansion + GELU of one wave row from its n1 fragment (the tail of chain_row)
 template <typename T, bool WG>
 __device__ inline void expand_gelu(const FwdW<T>& w, const typename Frag<T>::type& n1f, f32x4 g[2], f32x4 gp[2]) {
@@ -1609,7 +1621,7 @@ __global__ void __launch_bounds__(NT, sizeof(T) == 2 ? 4 : 1)
 cnx_apply_n1_kernel(PixArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Frag<T>::type frag_t;
-    typedef PixIO<T, JVP ? 4 : 2, JVP ? 2 : 1> IO;
+    typedef PixIO<T, JVP ? 4 : 2, JVP ? 2 : 1, JVP ? 2 : 3> IO;     // the primal-only kernel is memory-bound: two steps ahead
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, m = lane & 15;
@@ -1631,10 +1643,18 @@ cnx_apply_n1_kernel(PixArgs a) {
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 gq[2] = {z4, z4}, qdv[2] = {z4, z4}, sc14 = z4, sh4 = z4, scd4 = z4, shd4 = z4;
     __amdgpu_buffer_rsrc_t rs_o = make_rsrc(nullptr, 0), rs_od = make_rsrc(nullptr, 0);
-    io.request(0, ins, r, j * PIX_STEP + wave * PIX_WAVE);
+    // prologue: the first DEPTH steps' spans
+    PixPos ahead = {r, j};          // the next step to request
+    {
+        int64_t tt = t0;
+#pragma unroll
+        for (int d = 0; d < IO::DEPTH; ++d) {
+            if (tt < t1) { io.request(d, ins, ahead.r, ahead.j * PIX_STEP + wave * PIX_WAVE); ahead = pix_next(ahead, spi); ++tt; }
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int cur = 0, tgt = IO::DEPTH % (IO::DEPTH + 1);       // buffer of this step / of the step requested in it
     for (int64_t t = t0; t < t1; ++t) {
-        const int cur = (int)((t - t0) & 1);
         const int64_t rt = r, jt = j;
         if (++j == spi) { j = 0; ++r; }
         if (rt != rcur) {
@@ -1660,9 +1680,10 @@ cnx_apply_n1_kernel(PixArgs a) {
             if constexpr (JVP) rs_od = make_rsrc((const T*)a.od + rt * img, (uint32_t)(img * sizeof(T)));
         }
         __builtin_amdgcn_sched_barrier(0);
-        // next step's spans (past the end: this step again into the other buffer -- the instruction count stays fixed)
-        if (t + 1 < t1) io.request(cur ^ 1, ins, r, j * PIX_STEP + wave * PIX_WAVE);
-        else io.request(cur ^ 1, ins, rt, jt * PIX_STEP + wave * PIX_WAVE);
+        // the spans DEPTH steps ahead, into the buffer the previous step used (past the end: this step again -- the
+        // instruction count stays fixed)
+        if (t + IO::DEPTH < t1) { io.request(tgt, ins, ahead.r, ahead.j * PIX_STEP + wave * PIX_WAVE); ahead = pix_next(ahead, spi); }
+        else io.request(tgt, ins, rt, jt * PIX_STEP + wave * PIX_WAVE);
         __builtin_amdgcn_sched_barrier(0);
         const int64_t px0 = jt * PIX_STEP + wave * PIX_WAVE;
 #pragma unroll
@@ -1712,11 +1733,13 @@ cnx_apply_n1_kernel(PixArgs a) {
         io.store(0, rs_o, px0);
         if constexpr (JVP) io.store(1, rs_od, px0);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IO::S_VMEM) : "memory");   // this wave's next spans have landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IO::S_VMEM) : "memory");   // this wave's NEXT step's spans have landed
+        tgt = cur;
+        cur = cur + 1 == IO::DEPTH + 1 ? 0 : cur + 1;
     }
 }
 template <typename T> inline size_t lds_apply_n1_bytes(bool jvp) {
-    return (size_t)NWAVES * (jvp ? PixIO<T, 4, 2>::WAVE_BYTES : PixIO<T, 2, 1>::WAVE_BYTES);
+    return (size_t)NWAVES * (jvp ? PixIO<T, 4, 2, 2>::WAVE_BYTES : PixIO<T, 2, 1, 3>::WAVE_BYTES);
 }
 
 // MODE 0 / MODE 1 of cnx_bwd_kernel from n1 (and, MODE 1, its 1/sigma rho1).
@@ -1731,7 +1754,7 @@ __global__ void __launch_bounds__(NT, sizeof(T) == 2 ? (MODE == 0 ? 4 : 3) : 1)
 cnx_bwd_n1_kernel(PixArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Frag<T>::type frag_t;
-    typedef PixIO<T, 2, MODE == 1 ? 1 : 0> IO;       // in: n1, dout; out: dc1 (MODE 1)
+    typedef PixIO<T, 2, MODE == 1 ? 1 : 0, MODE == 1 ? 2 : 3> IO;       // in: n1, dout; out: dc1 (MODE 1); MODE 0 is memory-bound
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, m = lane & 15;
@@ -1817,13 +1840,18 @@ cnx_bwd_n1_kernel(PixArgs a) {
         lds_fence();
     };
     float rn[2] = {0.f, 0.f};
+    PixPos ahead = {r, j};          // the next step to request
     if (t0 < t1) {
         fetch_rho(r, j, rn);
-        io.request(0, ins, r, j * PIX_STEP + wave * PIX_WAVE);
+        int64_t tt = t0;
+#pragma unroll
+        for (int d = 0; d < IO::DEPTH; ++d) {
+            if (tt < t1) { io.request(d, ins, ahead.r, ahead.j * PIX_STEP + wave * PIX_WAVE); ahead = pix_next(ahead, spi); ++tt; }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int cur = 0, tgt = IO::DEPTH % (IO::DEPTH + 1);
     for (int64_t t = t0; t < t1; ++t) {
-        const int cur = (int)((t - t0) & 1);
         const float rho1[2] = {rn[0], rn[1]};
         if constexpr (MODE == 1) { land(rho1[0]); land(rho1[1]); }
         const int64_t rt = r, jt = j;
@@ -1845,13 +1873,9 @@ cnx_bwd_n1_kernel(PixArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         // next step: the 1/sigma loads first (older than the DMA: the counted wait below then covers them too), then the
         // spans (past the end: this step again into the other buffer -- the instruction count stays fixed)
-        if (t + 1 < t1) {
-            fetch_rho(r, j, rn);
-            io.request(cur ^ 1, ins, r, j * PIX_STEP + wave * PIX_WAVE);
-        } else {
-            fetch_rho(rt, jt, rn);
-            io.request(cur ^ 1, ins, rt, jt * PIX_STEP + wave * PIX_WAVE);
-        }
+        if (t + 1 < t1) fetch_rho(r, j, rn); else fetch_rho(rt, jt, rn);
+        if (t + IO::DEPTH < t1) { io.request(tgt, ins, ahead.r, ahead.j * PIX_STEP + wave * PIX_WAVE); ahead = pix_next(ahead, spi); }
+        else io.request(tgt, ins, rt, jt * PIX_STEP + wave * PIX_WAVE);
         __builtin_amdgcn_sched_barrier(0);
         const int64_t px0 = jt * PIX_STEP + wave * PIX_WAVE;
 #pragma unroll
@@ -1911,7 +1935,9 @@ cnx_bwd_n1_kernel(PixArgs a) {
         }
         if constexpr (MODE == 1) io.store(0, rs_dc, px0);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IO::S_VMEM) : "memory");   // this wave's next spans (and 1/sigma) have landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IO::S_VMEM) : "memory");   // this wave's NEXT step's spans (and 1/sigma) have landed
+        tgt = cur;
+        cur = cur + 1 == IO::DEPTH + 1 ? 0 : cur + 1;
     }
     if (rcur >= 0) flush_row();
     if constexpr (MODE == 0) {
@@ -1963,7 +1989,7 @@ cnx_bwd_n1_kernel(PixArgs a) {
     }
 }
 template <typename T> inline size_t lds_bwd_n1_bytes(int mode) {
-    const size_t io = (size_t)NWAVES * (mode == 1 ? PixIO<T, 2, 1>::WAVE_BYTES : PixIO<T, 2, 0>::WAVE_BYTES);
+    const size_t io = (size_t)NWAVES * (mode == 1 ? PixIO<T, 2, 1, 2>::WAVE_BYTES : PixIO<T, 2, 0, 3>::WAVE_BYTES);
     const size_t scratch = (size_t)REC_MAIN * sizeof(float);      // (MODE 0 uses its first NWAVES * REC_DQ floats)
     return io + scratch + (mode == 1 ? (size_t)NWAVES * WS_TILES * 16 * CS * sizeof(T) : 0);
 }
