@@ -167,6 +167,18 @@ def algorithmic_work(name, ints, nn):
             return es * px * 16 * 3, float(px) * (conv + 2 * exp + 2 * con + con + exp + con), dt
         if name == "mfc_cnx_bwd_conv":
             return es * px * 16 * 4, float(px) * 2 * conv, dt
+        # the same passes starting from a kept n1 ("from-n1 kernels"): the statistics pass also writes
+        # n1 (+ its tangent) and 4 bytes of 1/sigma per pixel; the others read n1 instead of repeating conv + LayerNorm
+        if name == "mfc_cnx_stats_save":
+            j = 2 if nn[1] else 1
+            return es * px * 16 * 2 * j + 4 * px, float(px) * (conv + exp) * j, dt
+        if name == "mfc_cnx_apply_n1":
+            j = 2 if nn[1] else 1
+            return es * px * 16 * 3 * j, float(px) * (exp + con) * j, dt
+        if name == "mfc_cnx_bwd_stats_n1":
+            return es * px * 16 * 2, float(px) * (exp + con), dt
+        if name == "mfc_cnx_bwd_main_n1":
+            return es * px * 16 * 3 + 4 * px, float(px) * (2 * exp + con + con + exp + con), dt
     if name == "mfc_adamw":
         dt, n = ints[0], ints[1]
         ges = 4 if dt == 0 else 2
@@ -202,6 +214,14 @@ def symbol_of(name, ints, nn):
         T = "float" if ints[0] == 0 else "unsigned short"
         if name in ("mfc_cnx_stats", "mfc_cnx_apply"):
             return f"cnx_fwd_kernel<{T}, {'true' if nn[1] else 'false'}, {0 if name == 'mfc_cnx_stats' else 1}>"
+        if name == "mfc_cnx_stats_save":
+            return f"cnx_fwd_kernel<{T}, {'true' if nn[1] else 'false'}, 0>"
+        if name == "mfc_cnx_apply_n1":
+            return f"cnx_apply_n1_kernel<{T}, {'true' if nn[1] else 'false'}>"
+        if name == "mfc_cnx_bwd_stats_n1":
+            return f"cnx_bwd_n1_kernel<{T}, 0>"
+        if name == "mfc_cnx_bwd_main_n1":
+            return f"cnx_bwd_n1_kernel<{T}, 1>"
         if name == "mfc_cnx_bwd_stats":
             return f"cnx_bwd_kernel<{T}, 0>"
         if name == "mfc_cnx_bwd_main":

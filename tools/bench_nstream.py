@@ -25,3 +25,12 @@ for M, R, tan in ((192, 128, True), (128, 128, False), (64, 64, False), (256, 12
     out.append(f"M={M}: plain {plain:.3f} ln{'+tan' if tan else ''} {ln:.3f}")
     del X, rho, C
 print(" | ".join(out))
+# the NT form (dX against a [S, 128] kernel): [R, 128] @ [S, 128]^T
+Wt = (torch.randn(S, 128, device=dev) * 0.05).bfloat16()
+out = []
+for M in (128, 64, 192):
+    X = (torch.randn(M, 128, device=dev) * 0.3).bfloat16()
+    C = torch.empty(M, S, device=dev, dtype=torch.bfloat16)
+    out.append(f"NT M={M}: {t(lambda: ops.gemm(X, Wt, trans_b=True, out=C)):.3f}")
+    del X, C
+print(" | ".join(out))
