@@ -2166,7 +2166,23 @@ enum CnxKind { K_STATS = 0, K_APPLY, K_STATS_JVP, K_APPLY_JVP, K_BWD_STATS, K_BW
 static const int64_t DEFAULT_BLOCKS[K_NKIND] = {3072, 3072, 2304, 512, 3072, 512, 768, 3072, 3072, 2304, 3072};
 inline bool kind_is_pix(int k) { return k >= K_APPLY_N1; }
 static int64_t MAX_BLOCKS = getenv("MFC_CNX_MAX_BLOCKS") ? atoll(getenv("MFC_CNX_MAX_BLOCKS")) : 0;   // 0: per-kernel defaults
-inline int64_t max_blocks(CnxKind k) { return MAX_BLOCKS > 0 ? MAX_BLOCKS : DEFAULT_BLOCKS[k]; }
+// MFC_CNX_BLOCKS="kind:n,kind:n": per-kernel overrides of the persistent grid (tuning sweeps; kind = CnxKind index)
+static int64_t KIND_BLOCKS[K_NKIND];
+static const bool KIND_BLOCKS_INIT = [] {
+    for (int k = 0; k < K_NKIND; ++k) KIND_BLOCKS[k] = 0;
+    const char* e = getenv("MFC_CNX_BLOCKS");
+    while (e && *e) {
+        char* end = nullptr;
+        const long k = strtol(e, &end, 10);
+        if (end == e || *end != ':') break;
+        const long n = strtol(end + 1, &end, 10);
+        if (k >= 0 && k < K_NKIND && n > 0) KIND_BLOCKS[k] = n;
+        e = (*end == ',') ? end + 1 : end;
+        if (*end != ',') break;
+    }
+    return true;
+}();
+inline int64_t max_blocks(CnxKind k) { return MAX_BLOCKS > 0 ? MAX_BLOCKS : (KIND_BLOCKS[k] > 0 ? KIND_BLOCKS[k] : DEFAULT_BLOCKS[k]); }
 constexpr int MAX_S = 8000;   // one [s, s, 16] fp32 image must stay below the 4 GiB a buffer resource addresses
 
 template <typename K, typename A>
