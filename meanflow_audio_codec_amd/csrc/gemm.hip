@@ -645,26 +645,17 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
             const int64_t rows_valid = mt[i] < 0 ? 0 : (g.M - row0 < 16 ? g.M - row0 : 16);
             const int64_t rows_bias = g.bias_rows - row0;      // rows [0, rows_bias) of the tile take the bias
             if (rows_bias > 0) {
-                const float hbf = lr < rows_bias ? 1.0f : 0.0f;        // (packed: v += bias * [row takes the bias])
-                const f32x2 hb2 = f32x2{hbf, hbf};
+                const bool hb = lr < rows_bias;
 #pragma unroll
                 for (int k4 = 0; k4 < 4; ++k4) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + lc + 4 * k4);
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const f32x2 o = __builtin_elementwise_fma(f32x2{b4[2 * h], b4[2 * h + 1]}, hb2,
-                                                                  f32x2{v[4 * k4 + 2 * h], v[4 * k4 + 2 * h + 1]});
-                        v[4 * k4 + 2 * h] = o[0]; v[4 * k4 + 2 * h + 1] = o[1];
-                    }
+                    for (int k = 0; k < 4; ++k) v[4 * k4 + k] += hb ? b4[k] : 0.f;
                 }
             }
             if (has_alpha) {
-                const f32x2 a2 = f32x2{g.alpha, g.alpha};
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const f32x2 o = f32x2{v[2 * k], v[2 * k + 1]} * a2;
-                    v[2 * k] = o[0]; v[2 * k + 1] = o[1];
-                }
+                for (int k = 0; k < 16; ++k) v[k] *= g.alpha;
             }
             if (kind[i] == 1) {
                 rho_pr = ln16_lane(v);
