@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collect the per-round evidence on the GPU box (run from the repo root through gpurun):
-#   tools/profile_round.sh r02_final
+#   tools/profile_round.sh r03_final
 # -> gpurun_out/<tag>/: default bench line, rocprofv3 kernel stats of the same command, the FETCH_SIZE / WRITE_SIZE
 #    PMC passes (separate runs, counters only) reduced by tools/pmc_traffic.py, and the decode path on its own.
 # Every step is its own process and a failure stops the sequence (no GPU step runs after a failed one).
 set -o pipefail
-TAG=${1:-r02_final}
+TAG=${1:-r03_final}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -28,5 +28,24 @@ python3 "$R/tools/pmc_traffic.py" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/$TAG" 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/decode_stats" -- python3 "$R/tools/bench_decode.py" 128 5 \
     > "$OUT/decode.json" 2> "$OUT/decode.log" || exit 6
 echo "[profile] decode stats done"
-find "$OUT" -name "*kernel_trace.csv" -size +20M -delete
+cd "$R" || exit 9
+# BASELINE configs #2 / #3 and the tokenizer alone (bench lines), then their kernel stats and the Mixer's SQ counters
+for w in mnist_mlp mnist_mixer mdct; do
+  timeout -k 10 200 python3 bench.py --workload $w --steps 20 --warmup 5 > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.log" || exit 7
+done
+echo "[profile] small workloads done"
+cd /tmp || exit 9
+for w in mnist_mlp mnist_mixer; do
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$w" -- python3 "$R/bench.py" --workload $w --steps 20 --warmup 5 --no-kernel-timing \
+      > "$OUT/bench_${w}_under_rocprof.json" 2> "$OUT/bench_${w}_under_rocprof.log" || exit 8
+done
+CNT="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"
+timeout -k 10 300 rocprofv3 --pmc $CNT -d "$OUT/sq_mixer" --output-format csv -- python3 "$R/bench.py" --workload mnist_mixer --steps 2 --warmup 1 --no-kernel-timing \
+    > "$OUT/sq_mixer.json" 2> "$OUT/sq_mixer.log" || exit 10
+python3 "$R/tools/sq_counters.py" "$OUT/sq_mixer" "$OUT/${TAG}_mixer_sq_counters.json" "^(gemm|adaln|gelu|colsum|transpose)" > "$OUT/sq_mixer_reduce.log" 2>&1 || exit 11
+echo "[profile] small-workload profiles done"
+cd "$R" || exit 9
+tools/profile_cnx_sq.sh "$TAG" > "$OUT/cnx_sq.log" 2>&1 || exit 12
+find "$OUT" "$R/gpurun_out/${TAG}_cnx_sq" -name "*kernel_trace.csv" -size +20M -delete
+find "$OUT" "$R/gpurun_out/${TAG}_cnx_sq" -name "*counter_collection.csv" -size +8M -delete
 ls -la "$OUT"
