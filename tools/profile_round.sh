@@ -10,12 +10,12 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-PMC_ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-decode --no-kernel-timing --no-overlap --no-loss-probe"
+PMC_ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-decode --no-kernel-timing --no-overlap --no-loss-probe --no-learn-probe"
 cd "$R" || exit 9
 timeout -k 10 400 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.log" || exit 1
 echo "[profile] default bench done"
 cd /tmp || exit 9
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/bench.py" --no-cpu-baseline --no-decode --no-loss-probe \
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/bench.py" --no-cpu-baseline --no-decode --no-loss-probe --no-learn-probe \
     > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.log" || exit 2
 echo "[profile] kernel stats done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" --output-format csv -- python3 "$R/bench.py" $PMC_ARGS \
