@@ -179,6 +179,17 @@ def algorithmic_work(name, ints, nn):
             return es * px * 16 * 2, float(px) * (exp + con), dt
         if name == "mfc_cnx_bwd_main_n1":
             return es * px * 16 * 3 + 4 * px, float(px) * (2 * exp + con + con + exp + con), dt
+    if name == "mfc_chanmlp_fwd":
+        # fused channel MLP of the Mixer: tokens in, residual in, tokens out; both Dense products per row (the tangent
+        # rows skip nothing: gelu'(h) hdot needs the same two products)
+        dt, rows, act, H = ints[:4]
+        es = 4 if dt == 0 else 2
+        return es * rows * 16 * 3 + es * 2 * 16 * H, 2.0 * (rows + (rows - act)) * 2 * 16 * H, dt
+    if name == "mfc_chanmlp_bwd":
+        # recomputes h (1 product), dG, da, dW1, dW2 (4 products)
+        dt, rows, H = ints[:3]
+        es = 4 if dt == 0 else 2
+        return es * rows * 16 * 3 + es * 4 * 16 * H, 2.0 * rows * 5 * 16 * H, dt
     if name == "mfc_adamw":
         dt, n = ints[0], ints[1]
         ges = 4 if dt == 0 else 2
@@ -227,6 +238,11 @@ def symbol_of(name, ints, nn):
         if name == "mfc_cnx_bwd_main":
             return f"cnx_bwd_kernel<{T}, 1>"
         return f"cnx_bwd_conv_kernel<{T}>"
+    if name == "mfc_chanmlp_fwd":
+        return f"chanmlp_fwd_kernel<{'float' if ints[0] == 0 else 'unsigned short'}>"
+    if name == "mfc_chanmlp_bwd":
+        H = ints[2]
+        return f"chanmlp_bwd_kernel<{'float' if ints[0] == 0 else 'unsigned short'}, {min(8, H // 128)}>"
     return name.replace("mfc_", "") + "_kernel"
 
 

@@ -41,7 +41,8 @@ extern "C" {
  * of mfc_sample_tr and mfc_flow_prepare, caller-owned workspaces instead of atomics (mfc_gemm_ws_elems,
  * mfc_cnx_ws_elems, MFC_FLOW_LOSS_WS_PER_ROW), colsum output of mfc_gemm_adamw.  Version 3 (round 3): additions only --
  * mfc_randn_dev (noise draw as a graph node); mfc_cnx_stats_save / mfc_cnx_apply_n1 / mfc_cnx_bwd_stats_n1 /
- * mfc_cnx_bwd_main_n1 (ConvNeXt passes from a kept n1); mfc_colsum_tall / mfc_colsum_ws_elems. */
+ * mfc_cnx_bwd_main_n1 (ConvNeXt passes from a kept n1); mfc_colsum_tall / mfc_colsum_ws_elems; mfc_chanmlp_fwd /
+ * mfc_chanmlp_bwd / mfc_chanmlp_ws_elems (fused channel MLP of the Mixer). */
 #define MFC_ABI_VERSION 3
 int mfc_abi_version(void);
 const char* mfc_build_info(void);
@@ -398,6 +399,21 @@ int mfc_copy2d(int dtype, int64_t rows, int64_t W, const void* src, int64_t lds,
  * MLPMixerBlock (models/mlp_mixer.py:80-84) with the residual add fused into the way back. */
 int mfc_transpose(int dtype, int64_t batch, int rows, int cols, const void* src, void* dst, float alpha,
                   const void* add, void* stream);
+
+/* Fused channel-mixing MLP of MLPMixerBlock on 16-channel tokens (models/mlp_mixer.py:66-94: Dense(channel_mix_dim) ->
+ * gelu -> Dense(num_channels), + residual), without the [rows, H] hidden activation ever reaching HBM:
+ *   out = gelu(a W1 + b1) W2 + b2 + res              a, res, out [rows, 16] dense; W1 [16, H]; W2 [H, 16]; b1 [H], b2 [16] fp32
+ * rows [act_rows, rows) are tangents of rows [0, rows - act_rows):  out = (gelu'(a_i W1 + b1) * (adot W1)) W2 + res.
+ * H % 16 == 0; res may be NULL.  a / res / out / b1 / b2 16-byte aligned. */
+int mfc_chanmlp_fwd(int dtype, int64_t rows, int64_t act_rows, int64_t H, const void* a, const void* W1, const float* b1,
+                    const void* W2, const float* b2, const void* res, void* out, void* stream);
+/* Its reverse pass (primal rows only), recomputing the hidden activation from a:
+ *   da [rows, 16] = (dy W2^T * gelu'(a W1 + b1)) W1^T;  dW1 [16, H], dW2 [H, 16] in `dtype`, db1 [H] fp32 (all OVERWRITTEN;
+ *   db2 = column sums of dy: mfc_colsum).  H in {128, 256, 512} or a multiple of 1024 (MFC_ENOSYS otherwise).
+ *   ws: mfc_chanmlp_ws_elems(rows, H) floats (per-workgroup partial sums, reduced in index order: no atomics). */
+int64_t mfc_chanmlp_ws_elems(int64_t rows, int64_t H);
+int mfc_chanmlp_bwd(int dtype, int64_t rows, int64_t H, const void* a, const void* dy, const void* W1, const float* b1,
+                    const void* W2, void* da, void* dW1, float* db1, void* dW2, float* ws, void* stream);
 
 #ifdef __cplusplus
 }

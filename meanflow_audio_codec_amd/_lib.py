@@ -82,6 +82,9 @@ SIGNATURES = {
                              _P]),
     "mfc_copy2d": (c_int, [c_int, c_int64, c_int64, _P, c_int64, _P, c_int64, c_float, c_int, _P]),
     "mfc_transpose": (c_int, [c_int, c_int64, c_int, c_int, _P, _P, c_float, _P, _P]),
+    "mfc_chanmlp_fwd": (c_int, [c_int, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfc_chanmlp_ws_elems": (c_int64, [c_int64, c_int64]),
+    "mfc_chanmlp_bwd": (c_int, [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_time_embed": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfc_sample_tr": (c_int, [c_uint64, c_uint64, c_int64, c_int64, c_int64, c_int64, c_float, c_float, c_int,
                               _P, _P, _P]),

@@ -12,11 +12,16 @@ docstrings expect; ``encode`` is wired to it here (reference defect
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
 from .. import _lib, ops
 from .common import dense, dense_dw, dense_dx, init_from_shapes
+
+
+# MFC_MIXER_FUSED=0: the channel MLP as two GEMMs + gelu kernels (A/B runs and the cross-check test)
+_FUSED_CHANNEL_MLP = os.environ.get("MFC_MIXER_FUSED", "1") != "0"
 
 
 def _mixer_shapes(prefix, nt, C, cond_dim, tmd, cmd):
@@ -51,24 +56,40 @@ class _MixerBlock:
         x1 = ops.transpose(tk, N, C, nt, add=X).view(N * nt, C)                                 # + residual
         mod2 = self._mod(w, "Dense_3", cstack, R)
         a2 = ops.adaln_fwd(x1, mod2[:, :C], mod2[:, C:], act_rows=R * nt, mod_div=nt)
-        h2 = dense(a2, w[f"{p}/Dense_4/kernel"], w[f"{p}/Dense_4/bias"], bias_rows=R * nt)
-        g2 = ops.gelu_fwd(h2, act_rows=R * nt)
-        x2 = dense(g2, w[f"{p}/Dense_5/kernel"], w[f"{p}/Dense_5/bias"], bias_rows=R * nt, residual=x1, beta=1.0)
+        W4, W5 = w[f"{p}/Dense_4/kernel"], w[f"{p}/Dense_5/kernel"]
+        if self.fused_channel_mlp(W4):
+            # 16-channel tokens: both Dense layers, the gelu and the residual in one kernel; the [N*nt, channel_mix_dim]
+            # hidden activation is neither written nor saved (the reverse kernel recomputes it from a2)
+            x2 = ops.chanmlp_fwd(a2, W4, w[f"{p}/Dense_4/bias"], W5, w[f"{p}/Dense_5/bias"], act_rows=R * nt, residual=x1)
+            h2 = g2 = None
+        else:
+            h2 = dense(a2, W4, w[f"{p}/Dense_4/bias"], bias_rows=R * nt)
+            g2 = ops.gelu_fwd(h2, act_rows=R * nt)
+            x2 = dense(g2, W5, w[f"{p}/Dense_5/bias"], bias_rows=R * nt, residual=x1, beta=1.0)
         saved = (X, mod1, aT, h, g, x1, mod2, a2, h2, g2) if save else None
         return x2, saved
+
+    def fused_channel_mlp(self, W4) -> bool:
+        return _FUSED_CHANNEL_MLP and ops.chanmlp_ok(self.C, W4.shape[1]) and W4.dtype == self.T
 
     def backward(self, w, saved, dx2, cond, R, grads):
         """dx2 [R*nt, C] -> (dX [R*nt, C], dcond [R, cond] fp32); parameter gradients into ``grads``."""
         p, nt, C, T = self.p, self.nt, self.C, self.T
         X, mod1, aT, h, g, x1, mod2, a2, h2, g2 = saved
-        X, x1, a2, h2, g2 = X[:R * nt], x1[:R * nt], a2[:R * nt], h2[:R * nt], g2[:R * nt]
+        X, x1, a2 = X[:R * nt], x1[:R * nt], a2[:R * nt]
         aT, h, g = aT[:R * C], h[:R * C], g[:R * C]
         dev = dx2.device
         # channel mixing: x2 = mlp(adaln(x1)) + x1
-        dense_dw(g2, dx2, out=grads[f"{p}/Dense_5/kernel"]); ops.colsum(dx2, out=grads[f"{p}/Dense_5/bias"])
-        dh2 = ops.gelu_bwd(h2, dense_dx(dx2, w[f"{p}/Dense_5/kernel"]))
-        dense_dw(a2, dh2, out=grads[f"{p}/Dense_4/kernel"]); ops.colsum(dh2, out=grads[f"{p}/Dense_4/bias"])
-        da2 = dense_dx(dh2, w[f"{p}/Dense_4/kernel"])
+        if h2 is None:
+            ops.colsum(dx2, out=grads[f"{p}/Dense_5/bias"])
+            da2 = ops.chanmlp_bwd(a2, dx2.contiguous(), w[f"{p}/Dense_4/kernel"], w[f"{p}/Dense_4/bias"], w[f"{p}/Dense_5/kernel"],
+                                  grads[f"{p}/Dense_4/kernel"], grads[f"{p}/Dense_4/bias"], grads[f"{p}/Dense_5/kernel"])
+        else:
+            h2, g2 = h2[:R * nt], g2[:R * nt]
+            dense_dw(g2, dx2, out=grads[f"{p}/Dense_5/kernel"]); ops.colsum(dx2, out=grads[f"{p}/Dense_5/bias"])
+            dh2 = ops.gelu_bwd(h2, dense_dx(dx2, w[f"{p}/Dense_5/kernel"]))
+            dense_dw(a2, dh2, out=grads[f"{p}/Dense_4/kernel"]); ops.colsum(dh2, out=grads[f"{p}/Dense_4/bias"])
+            da2 = dense_dx(dh2, w[f"{p}/Dense_4/kernel"])
         dmod2 = torch.empty((R, 2 * C), dtype=torch.float32, device=dev)
         dx1 = ops.adaln_bwd(x1, mod2[:R, :C], da2, dmod2[:, :C], dmod2[:, C:], mod_div=nt)
         dx1 = ops.axpby(1.0, dx1, 1.0, dx2)

@@ -534,6 +534,47 @@ def gate_bwd(dy, o, s2, inv_k, ds2, do=None):
     return do
 
 
+def chanmlp_ok(C: int, H: int) -> bool:
+    """Shapes the fused channel MLP takes (forward and reverse): 16 channels, H in {128, 256, 512} or a multiple of 1024."""
+    return C == 16 and (H in (128, 256, 512) or (H > 0 and H % 1024 == 0 and H <= 16384))
+
+
+def chanmlp_fwd(a, W1, b1, W2, b2, act_rows=None, residual=None, out=None):
+    """out = gelu(a W1 + b1) W2 + b2 + residual on [rows, 16] tokens (rows >= act_rows: tangents), the hidden
+    activation kept in registers (mfc_chanmlp_fwd; models/mlp_mixer.py:66-94)."""
+    rows, C = a.shape
+    H = W1.shape[1]
+    assert C == 16 and W1.shape == (16, H) and W2.shape == (H, 16) and a.is_contiguous()
+    assert W1.dtype == a.dtype and W2.dtype == a.dtype and W1.is_contiguous() and W2.is_contiguous()
+    assert b1.dtype == torch.float32 and b2.dtype == torch.float32
+    if out is None:
+        out = torch.empty_like(a)
+    assert residual is None or (residual.shape == a.shape and residual.is_contiguous() and residual.dtype == a.dtype)
+    _lib.check(_lib.lib().mfc_chanmlp_fwd(_lib.dtype_code(a.dtype), rows, rows if act_rows is None else act_rows, H,
+                                          a.data_ptr(), W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(),
+                                          _lib.ptr(residual), out.data_ptr(), _lib.stream_ptr()), "mfc_chanmlp_fwd")
+    return out
+
+
+def chanmlp_bwd(a, dy, W1, b1, W2, dW1, db1, dW2, da=None):
+    """Reverse of chanmlp_fwd on the primal rows: returns da; dW1 / db1 / dW2 are overwritten (mfc_chanmlp_bwd)."""
+    rows, C = a.shape
+    H = W1.shape[1]
+    assert C == 16 and dy.shape == a.shape and a.is_contiguous() and dy.is_contiguous() and dy.dtype == a.dtype
+    assert dW1.shape == W1.shape and dW2.shape == W2.shape and dW1.dtype == a.dtype and dW2.dtype == a.dtype
+    assert dW1.is_contiguous() and dW2.is_contiguous() and db1.dtype == torch.float32 and db1.numel() == H
+    if da is None:
+        da = torch.empty_like(a)
+    n = _lib.lib().mfc_chanmlp_ws_elems(rows, H)
+    if n < 0:
+        raise _lib.MfcError(f"mfc_chanmlp_bwd: unsupported hidden width {H}")
+    ws = torch.empty(n, dtype=torch.float32, device=a.device)      # caching allocator: stream-ordered reuse
+    _lib.check(_lib.lib().mfc_chanmlp_bwd(_lib.dtype_code(a.dtype), rows, H, a.data_ptr(), dy.data_ptr(), W1.data_ptr(),
+                                          b1.data_ptr(), W2.data_ptr(), da.data_ptr(), dW1.data_ptr(), db1.data_ptr(),
+                                          dW2.data_ptr(), ws.data_ptr(), _lib.stream_ptr()), "mfc_chanmlp_bwd")
+    return da
+
+
 def copy2d(src, dst, alpha=1.0, accumulate=False):
     _v2(src), _v2(dst)
     assert src.shape == dst.shape and src.dtype == dst.dtype
