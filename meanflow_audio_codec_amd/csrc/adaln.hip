@@ -116,7 +116,6 @@ __global__ void __launch_bounds__(AT) adaln_bwd_kernel(AdaArgs a) {
 constexpr int MOD_BATCH = 1024;
 template <typename T>
 __global__ void __launch_bounds__(AT) adaln_bwd_mod_kernel(AdaArgs a) {
-    __shared__ float red[AT / 64];
     __shared__ float st_mean[MOD_BATCH], st_rho[MOD_BATCH];
     const int64_t grp = blockIdx.x, W = a.W;
     const int64_t r0 = grp * a.mod_div, r1 = (r0 + a.mod_div < a.rows) ? r0 + a.mod_div : a.rows;
@@ -124,17 +123,21 @@ __global__ void __launch_bounds__(AT) adaln_bwd_mod_kernel(AdaArgs a) {
     float* dh = (float*)a.dshift + grp * a.ldd;
     for (int64_t b0 = r0; b0 < r1; b0 += MOD_BATCH) {
         const int nb = (int)((r1 - b0 < MOD_BATCH) ? r1 - b0 : MOD_BATCH);
-        for (int i = 0; i < nb; ++i) {
+        // statistics: one WAVE per row (butterfly sums, no workgroup barrier per row -- with a barrier pair per reduction
+        // the encoder's 544-token groups spent 0.6 ms here)
+        for (int i = threadIdx.x >> 6; i < nb; i += AT / 64) {
             const T* xp = (const T*)a.x + (b0 + i) * a.ldx;
             float s = 0.f, ss = 0.f;
-            for (int64_t c = threadIdx.x; c < W; c += AT) { const float v = St<T>::ld(xp + c); s += v; ss += v * v; }
-            const float mean = block_sum(s, red) / (float)W;
-            const float var = fmaxf(0.f, block_sum(ss, red) / (float)W - mean * mean);
-            if (threadIdx.x == 0) { st_mean[i] = mean; st_rho[i] = rsqrtf(var + 1e-6f); }
+            for (int64_t c = threadIdx.x & 63; c < W; c += 64) { const float v = St<T>::ld(xp + c); s += v; ss += v * v; }
+            for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+            const float mean = s / (float)W;
+            const float var = fmaxf(0.f, ss / (float)W - mean * mean);
+            if ((threadIdx.x & 63) == 0) { st_mean[i] = mean; st_rho[i] = rsqrtf(var + 1e-6f); }
         }
         __syncthreads();
         for (int64_t c = threadIdx.x; c < W; c += AT) {
             float acc_s = (b0 == r0) ? 0.f : ds[c], acc_h = (b0 == r0) ? 0.f : dh[c];
+#pragma unroll 8
             for (int i = 0; i < nb; ++i) {
                 const float n = (St<T>::ld((const T*)a.x + (b0 + i) * a.ldx + c) - st_mean[i]) * st_rho[i];
                 const float dyv = St<T>::ld((const T*)a.dy + (b0 + i) * a.ldy + c);

@@ -100,3 +100,66 @@ def test_sharded_optimizer_two_ranks_one_gpu():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _rccl_worker(port, q):
+    """One rank, backend "nccl" (= RCCL on ROCm): every collective of the data-parallel step runs through RCCL itself --
+    communicator creation, bf16 reduce-scatter, AdamW on the (whole) slice, the in-place all-gather with its event hand-over
+    to the next forward, fp32 / bf16 all-reduce, async handles.  With one rank each collective is the identity, so the
+    sharded schedule must reproduce the plain single-GPU step bit for bit."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    except Exception as e:  # pragma: no cover
+        q.put(("init-failed", repr(e)[-800:]))
+        return
+    try:
+        from meanflow_audio_codec_amd.distributed import GradReducer
+        assert dist.get_backend() == "nccl"
+        ref, _, loss_ref = _run(0, 1, shard=False, overlap=False)
+        for overlap in (False, True):
+            class Forced(GradReducer):          # world-1 gating off: take the RCCL path although it is the identity
+                def __init__(self, **kw):
+                    super().__init__(**kw)
+                    self.shard_optimizer = self.defer_gather = self._native = True
+            import meanflow_audio_codec_amd.distributed as D
+            orig = D.GradReducer
+            D.GradReducer = Forced
+            try:
+                st, red, loss = _run(0, 1, shard=True, overlap=overlap)
+            finally:
+                D.GradReducer = orig
+            assert red._native and sum(k.startswith("blocks_") for k in red.sharded) == 8, sorted(red.sharded)
+            assert loss == loss_ref
+            for k in st.params:
+                assert torch.equal(st.params[k], ref.params[k]), k
+                assert torch.equal(st.work[k], ref.work[k]), k
+        # the plain exchange: bf16 and fp32 all-reduce, blocking and async, are the identity at one rank
+        g = torch.Generator(device="cuda").manual_seed(1)
+        for dt in (torch.bfloat16, torch.float32):
+            t = torch.randn(1 << 22, device="cuda", generator=g).to(dt)
+            t0 = t.clone()
+            dist.all_reduce(t)
+            h = dist.all_reduce(t, async_op=True)
+            h.wait()
+            torch.cuda.synchronize()
+            assert torch.equal(t, t0)
+        q.put(("ok", torch.cuda.nccl.version() if hasattr(torch.cuda, "nccl") else None))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("failed", traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_execute_on_one_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert res[0] == "ok", res
+    print("RCCL version", res[1])

@@ -42,7 +42,7 @@ done
 CNT="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"
 timeout -k 10 300 rocprofv3 --pmc $CNT -d "$OUT/sq_mixer" --output-format csv -- python3 "$R/bench.py" --workload mnist_mixer --steps 2 --warmup 1 --no-kernel-timing \
     > "$OUT/sq_mixer.json" 2> "$OUT/sq_mixer.log" || exit 10
-python3 "$R/tools/sq_counters.py" "$OUT/sq_mixer" "$OUT/${TAG}_mixer_sq_counters.json" "^(gemm|adaln|gelu|colsum|transpose)" > "$OUT/sq_mixer_reduce.log" 2>&1 || exit 11
+python3 "$R/tools/sq_counters.py" "$OUT/sq_mixer" "$OUT/${TAG}_mixer_sq_counters.json" "^(gemm|adaln|gelu|colsum|transpose|chanmlp)" > "$OUT/sq_mixer_reduce.log" 2>&1 || exit 11
 echo "[profile] small-workload profiles done"
 cd "$R" || exit 9
 tools/profile_cnx_sq.sh "$TAG" > "$OUT/cnx_sq.log" 2>&1 || exit 12
