@@ -285,7 +285,10 @@ gemm_kernel(GemmArgs g) {
     constexpr int MI = BMT / 32;          // 16-row MFMA tiles per wave along M (waves are 2 x 2)
     // operand tiles: [128][LDK] when the source is K-contiguous, [BK][LDR] when it is row-contiguous
     constexpr int TEA = tile_elems(BK, sizeof(T), BMT > 128 ? BMT : 128), TE = tile_elems(BK, sizeof(T));
-    __shared__ __attribute__((aligned(16))) T lds[TEA + TE];
+#ifndef MFC_GEMM_LDS_PAD
+#define MFC_GEMM_LDS_PAD 0     // occupancy probe (compile-time): unused extra LDS bytes per workgroup
+#endif
+    __shared__ __attribute__((aligned(16))) T lds[TEA + TE + MFC_GEMM_LDS_PAD / sizeof(T)];
     T* As = lds;
     T* Bs = lds + TEA;
     typedef typename Frag<T>::type frag_t;
