@@ -817,6 +817,64 @@ def _executed_flops(rows):
     return tot
 
 
+def cpu_baseline_small(wl, B, warmup=3, timed=10):
+    """cpu_baseline of BASELINE configs #2 / #3 (kind "port"): the oracle's whole step -- loss, reverse pass (and the
+    forward-mode tangent of the MeanFlow objective), AdamW -- at the config's own shape in fp32 on the host cores;
+    BASELINE.md section 3's method (3 warm-up + 10 timed steps, mean +- std).  The Mixer is timed at batch 16: autograd +
+    ``torch.func.jvp`` keep ~1.3 GB of [tokens, 2048] activations per sample alive (166 GB at the config's 128); its
+    samples/s is that batch over the step time, unscaled (AdamW's share, which does not grow with the batch, is included
+    in full, so the figure if anything understates the CPU at batch 128)."""
+    if wl["arch"] != "mlp":
+        B = min(B, 16)
+    from oracle import flow_oracle as fo
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    D = wl["D"]
+    if wl["arch"] == "mlp":
+        shapes = fo.mlp_flow_shapes(D, wl["cond"], wl["latent"], wl["blocks"])
+        apply, encode = fo.mlp_flow_apply, fo.mlp_flow_encode
+    else:
+        shapes = fo.mixer_flow_shapes(D, wl["cond"], wl["latent"], wl["blocks"])
+        apply, encode = fo.mixer_flow_apply, fo.mixer_encode
+    params = fo.init_params(shapes, seed=0, dtype=torch.float32)
+    flat = fo.flatten(params)
+    m = {k: torch.zeros_like(v) for k, v in flat.items()}
+    v = {k: torch.zeros_like(p) for k, p in flat.items()}
+    g = torch.Generator().manual_seed(0)
+    x, e = torch.rand(B, D, generator=g), torch.randn(B, D, generator=g)
+    t, r = fo.sample_tr_from_normals(torch.randn(B, 1, generator=g), torch.randn(B, 1, generator=g))
+    t, r = t.float(), r.float()
+    ts = []
+    i = -1
+    while i + 1 < warmup + timed:
+        i += 1
+        t0 = time.perf_counter()
+        if wl["arch"] == "mlp":
+            loss, grads, _ = fo.fm_loss(apply, encode, params, x, e, t)
+        else:
+            loss, grads, _ = fo.mf_loss(apply, encode, params, x, e, t, r)
+        gf = fo.flatten(grads)
+        for k in flat:
+            flat[k], m[k], v[k] = fo.adamw_step(flat[k], gf[k], m[k], v[k], i + 1, 1e-4, 1e-4)
+        params = fo.unflatten(flat)
+        dt = time.perf_counter() - t0
+        if i == 0 and dt * (warmup + timed) > 120.0:
+            warmup, timed = 1, 3          # bounded sample: a step of several seconds is timed 1 + 3 times instead of 3 + 10
+        log(f"cpu baseline ({wl['arch']}): {'warm-up' if i < warmup else 'timed'} step {i}: {dt:.2f} s")
+        if i >= warmup:
+            ts.append(dt)
+    mean, sd = _mean_std(ts)
+    return {"value": round(B / mean, 3), "unit": "samples/s", "cores": cores, "kind": "port", "cpu": _cpu_model(),
+            "value_std": round(B * sd / mean ** 2, 3), "step_s": round(mean, 4), "step_s_std": round(sd, 4),
+            "timed_steps": timed, "warmup_steps": warmup,
+            "sample": f"oracle/flow_oracle.py {'fm_loss' if wl['arch'] == 'mlp' else 'mf_loss'} + adamw_step on {cores} threads, fp32, the config's "
+                      f"own shape (D={D}) and batch {B}: {warmup} warm-up + {timed} timed steps, unscaled"}
+
+
 def run_small(args):
     """BASELINE configs #2 / #3 (single GPU, B = 128; SURVEY 8d: fp32, MFMA-bound at this batch): one step =
     tokenise -> loss (forward, tangent where the method has one, reverse) -> AdamW, inputs resident in HBM."""
@@ -909,6 +967,13 @@ def run_small(args):
         out["top_kernels"] = [dict(kernel=kernel_of(r["name"], r["ints"]), per_step_ms=round(r["per_step_ms"], 4),
                                    launches=r["launches"], avg_ms=round(r["avg_ms"], 5), **(roofline_of(r, args.dtype) or {}))
                               for r in rows[:30]]
+    if not args.no_cpu_baseline:
+        del state, params
+        torch.cuda.empty_cache()
+        try:
+            out["cpu_baseline"] = cpu_baseline_small(wl, B, args.cpu_warmup, args.cpu_steps)
+        except Exception as ex:  # report, never hide
+            out["cpu_baseline"] = {"error": repr(ex)[:300]}
     print(json.dumps(out), flush=True)
 
 
@@ -962,6 +1027,23 @@ def run_mdct(args):
                         "unit": "GB/s", "frac": round(wi[0] / (i["avg_ms"] * 1e-3) / HBM_PEAK, 4), "traffic": None},
            "round_trip_max_abs_err_vs_2x": roundtrip, "round_trip_samples": [lo_, hi_],
            "round_trip_max_abs_err_incl_partially_covered_edges": roundtrip_edges, "env": mfc_env()}
+    if not args.no_cpu_baseline:
+        # the oracle's float32 restatement of the reference's direct (matmul) MDCT / IMDCT on a bounded sample of the same
+        # clips: numpy, BLAS threads as the host gives them
+        from oracle import mdct_oracle as mo
+        nb = 8
+        xs = x[:nb].cpu().numpy()
+        mo.imdct_f32(mo.mdct_f32(xs[:1], N_, hop_), N_, hop_)          # warm-up (basis, BLAS)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            mo.imdct_f32(mo.mdct_f32(xs, N_, hop_), N_, hop_)
+            ts.append(time.perf_counter() - t0)
+        mean, sd = _mean_std(ts)
+        out["cpu_baseline"] = {"value": round(nb / mean, 2), "unit": "clips/s", "cores": max(1, min(len(os.sched_getaffinity(0)), 16)),
+                               "kind": "port", "cpu": _cpu_model(), "value_std": round(nb * sd / mean ** 2, 2),
+                               "sample": f"oracle/mdct_oracle.py mdct_f32 + imdct_f32 (the reference's direct definition as matmuls) on {nb} of the "
+                                         f"{B} clips, 1 warm-up + 3 timed pairs, unscaled"}
     print(json.dumps(out), flush=True)
 
 

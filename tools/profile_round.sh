@@ -31,16 +31,16 @@ echo "[profile] decode stats done"
 cd "$R" || exit 9
 # BASELINE configs #2 / #3 and the tokenizer alone (bench lines), then their kernel stats and the Mixer's SQ counters
 for w in mnist_mlp mnist_mixer mdct; do
-  timeout -k 10 200 python3 bench.py --workload $w --steps 20 --warmup 5 > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.log" || exit 7
+  timeout -k 10 500 python3 bench.py --workload $w --steps 20 --warmup 5 > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.log" || exit 7
 done
 echo "[profile] small workloads done"
 cd /tmp || exit 9
 for w in mnist_mlp mnist_mixer; do
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$w" -- python3 "$R/bench.py" --workload $w --steps 20 --warmup 5 --no-kernel-timing \
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$w" -- python3 "$R/bench.py" --workload $w --steps 20 --warmup 5 --no-kernel-timing --no-cpu-baseline \
       > "$OUT/bench_${w}_under_rocprof.json" 2> "$OUT/bench_${w}_under_rocprof.log" || exit 8
 done
 CNT="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"
-timeout -k 10 300 rocprofv3 --pmc $CNT -d "$OUT/sq_mixer" --output-format csv -- python3 "$R/bench.py" --workload mnist_mixer --steps 2 --warmup 1 --no-kernel-timing \
+timeout -k 10 300 rocprofv3 --pmc $CNT -d "$OUT/sq_mixer" --output-format csv -- python3 "$R/bench.py" --workload mnist_mixer --steps 2 --warmup 1 --no-kernel-timing --no-cpu-baseline \
     > "$OUT/sq_mixer.json" 2> "$OUT/sq_mixer.log" || exit 10
 python3 "$R/tools/sq_counters.py" "$OUT/sq_mixer" "$OUT/${TAG}_mixer_sq_counters.json" "^(gemm|adaln|gelu|colsum|transpose|chanmlp)" > "$OUT/sq_mixer_reduce.log" 2>&1 || exit 11
 echo "[profile] small-workload profiles done"
