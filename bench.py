@@ -246,12 +246,12 @@ def symbol_of(name, ints, nn):
     return name.replace("mfc_", "") + "_kernel"
 
 
-PMC_TABLE = "r02_final_pmc_traffic.json"
+PMC_TABLE = "r03_final_pmc_traffic.json"
 
 
 def measured_traffic(symbol):
     """average HBM bytes per launch of a kernel symbol from the committed rocprofv3 PMC passes of this round
-    (profiles/r02_final_pmc_traffic.json, made by tools/pmc_traffic.py), or None."""
+    (profiles/r03_final_pmc_traffic.json, made by tools/pmc_traffic.py), or None."""
     try:
         with open(os.path.join(ROOT, "profiles", PMC_TABLE)) as f:
             tab = json.load(f)
