@@ -180,11 +180,11 @@ def algorithmic_work(name, ints, nn):
         if name == "mfc_cnx_bwd_main_n1":
             return es * px * 16 * 3 + 4 * px, float(px) * (2 * exp + con + con + exp + con), dt
     if name == "mfc_chanmlp_fwd":
-        # fused channel MLP of the Mixer: tokens in, residual in, tokens out; both Dense products per row (the tangent
-        # rows skip nothing: gelu'(h) hdot needs the same two products)
+        # fused channel MLP of the Mixer: tokens in, residual in, tokens out; two Dense products per row, primal or tangent
+        # (a tangent row's are hdot = adot W1 and (gelu'(h) hdot) W2; the primal h it needs belongs to its primal row)
         dt, rows, act, H = ints[:4]
         es = 4 if dt == 0 else 2
-        return es * rows * 16 * 3 + es * 2 * 16 * H, 2.0 * (rows + (rows - act)) * 2 * 16 * H, dt
+        return es * rows * 16 * 3 + es * 2 * 16 * H, 2.0 * rows * 2 * 16 * H, dt
     if name == "mfc_chanmlp_bwd":
         # recomputes h (1 product), dG, da, dW1, dW2 (4 products)
         dt, rows, H = ints[:3]
@@ -556,6 +556,12 @@ def run_convflow(args):
     if os.environ.get("MFC_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
     backend = os.environ.get("MFC_DIST_BACKEND", "nccl")
+    if world > 1:
+        # single node, one process per GPU: dmabuf IPC (what RCCL's P2P needs on this pool) and the loopback interface for
+        # RCCL's bootstrap sockets (the boxes carry dozens of virtual interfaces; the data path is xGMI either way) -- both
+        # before the first HIP call, both only if the launcher did not decide otherwise
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
