@@ -11,7 +11,7 @@
 // v_mfma_f32_16x16x4_f32 (the exact fp32 chain the tiled GEMM uses), bf16 storage on v_mfma_f32_16x16x16_bf16.
 //   forward : one wave = two 16-row tiles (+ the tangent rows of the same tokens: gelu'(h) * hdot), loop over H / 16 hidden tiles
 //   reverse : recomputes h from a; one workgroup = 8 waves that split H (1024 of it per pass) between them and keep d W1 / d W2 /
-//             d b1 of their hidden range in registers over all the workgroup's rows; d a is summed over the waves through LDS in wave
+//             d b1 of their hidden range in registers over all the workgroup's rows, two 16-row tiles per step; d a is summed over the waves through LDS in wave
 //             order; per-workgroup records are reduced in index order by a second kernel (no atomics: bitwise reproducible).
 // Weight fragments are read straight from W1 / W2 (L2-resident: 256 KB) -- no packing pass, no workspace for them.
 #include "mfc_common.h"
@@ -191,11 +191,11 @@ struct CmBwdArgs {
 //   dW1^T [hidden x ch] += dH^T a A: dH[row 4q+s][hidden r] (same)                             B: a[row 4q+s][ch r]
 //   db1 [hidden r] += sum_s dH[row 4q+s][hidden r]   (per-lane partial over the lane's 4 rows; the 4 q's are summed at the flush)
 // Rows past `rows` load zeros: dy = 0 there, so every contribution vanishes.
-template <typename T, int TPW>
+template <typename T, int TPW, int RG = 2>
 __global__ void __launch_bounds__(64 * CM_BW) chanmlp_bwd_kernel(CmBwdArgs g) {
     typedef typename CmIO<T>::frag frag_t;
-    __shared__ __attribute__((aligned(16))) float tr[CM_BW][2][16 * CM_TLD];
-    __shared__ __attribute__((aligned(16))) float red[CM_BW][256];
+    __shared__ __attribute__((aligned(16))) float tr[CM_BW][4 * RG][16 * CM_TLD];      // per wave: G / dH transposes, then a^T / dy^T
+    __shared__ __attribute__((aligned(16))) float red[2][CM_BW * RG][256];
     const int lane = threadIdx.x & 63, q = lane >> 4, r = lane & 15;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const T* a = (const T*)g.a;
@@ -208,10 +208,9 @@ __global__ void __launch_bounds__(64 * CM_BW) chanmlp_bwd_kernel(CmBwdArgs g) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) vo1[s] = (uint32_t)(((4 * q + s) * H + r) * ES);
     const uint32_t vo3 = (uint32_t)((r * CM_C + 4 * q) * ES), vo4 = (uint32_t)((r * H + 4 * q) * ES), vob = (uint32_t)(4 * q * 4);
-    float* trG = &tr[w][0][0];
-    float* trD = &tr[w][1][0];
-    const int64_t ntiles = (g.rows + 15) / 16;
+    const int64_t ngroups = (g.rows + 16 * RG - 1) / (16 * RG);
     float* rec = g.ws + (int64_t)blockIdx.x * (2 * H * CM_C + H);
+    int par = 0;
     // H = npass x (8 waves x TPW tiles x 16): a pass walks all the workgroup's rows for one slice of the hidden range (the
     // accumulators of 16 tiles per wave do not fit 256 VGPRs); d a of the earlier passes waits in fp32 in `dascr`, which
     // only this workgroup touches for its rows
@@ -221,24 +220,34 @@ __global__ void __launch_bounds__(64 * CM_BW) chanmlp_bwd_kernel(CmBwdArgs g) {
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) { dW1a[tt] = f32x4{0.f, 0.f, 0.f, 0.f}; dW2a[tt] = f32x4{0.f, 0.f, 0.f, 0.f}; dba[tt] = 0.f; }
     const uint32_t hw = 16u * (uint32_t)((pass * CM_BW + w) * TPW);
-    for (int64_t rt = blockIdx.x; rt < ntiles; rt += gridDim.x) {
-        const int64_t row0 = rt * 16;
-        const bool ok1 = row0 + r < g.rows;
-        const frag_t aB1 = ok1 ? CmIO<T>::ld(a + (row0 + r) * CM_C + 4 * q) : CmIO<T>::zero();
-        const frag_t dyB1 = ok1 ? CmIO<T>::ld(dy + (row0 + r) * CM_C + 4 * q) : CmIO<T>::zero();
-        frag_t aB2, dyB2;        // k = rows 4q..4q+3, column = channel r
-        {
-            float av[4], dv[4];
+    // RG row tiles per step: the token rows come from HBM and the wait for them (and, from the second pass on, for the
+    // parked d a) is exposed once per step -- measured ~3.7 us per step against ~1 us of products per hidden tile -- so a
+    // step carries as many row tiles as the registers allow; the weight fragments of a hidden tile serve all of them
+    for (int64_t rg = blockIdx.x; rg < ngroups; rg += gridDim.x) {
+        // The token rows as B operands with k = channels (aB1 / dyB1: lane (q, r) = row r, channels 4q..4q+3, one 16-byte
+        // load) stay in registers for the whole step.  The contraction over rows needs them with k = rows 4q..4q+3, column =
+        // channel r: each wave parks a transposed fp32 copy [channel][row] in its own LDS slab once per step and reads the
+        // fragment back per use (one ds_read_b128) -- 16 VGPRs less than holding it, and no strided global gather.
+        frag_t aB1[RG], dyB1[RG];
+        f32x4 da_acc[RG];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int64_t row = row0 + 4 * q + s;
-                av[s] = row < g.rows ? St<T>::ld(a + row * CM_C + r) : 0.f;
-                dv[s] = row < g.rows ? St<T>::ld(dy + row * CM_C + r) : 0.f;
+        for (int i = 0; i < RG; ++i) {
+            const int64_t row0 = (rg * RG + i) * 16;
+            const bool ok1 = row0 + r < g.rows;
+            aB1[i] = ok1 ? CmIO<T>::ld(a + (row0 + r) * CM_C + 4 * q) : CmIO<T>::zero();
+            dyB1[i] = ok1 ? CmIO<T>::ld(dy + (row0 + r) * CM_C + 4 * q) : CmIO<T>::zero();
+            const f32x4 av = CmIO<T>::f32(aB1[i]), dv = CmIO<T>::f32(dyB1[i]);
+            float* aT = &tr[w][2 * RG + 2 * i][0];
+            float* dT = &tr[w][2 * RG + 2 * i + 1][0];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                aT[(4 * q + e) * CM_TLD + r] = av[e];
+                dT[(4 * q + e) * CM_TLD + r] = dv[e];
             }
-            make_frag(aB2, av[0], av[1], av[2], av[3]);
-            make_frag(dyB2, dv[0], dv[1], dv[2], dv[3]);
+            da_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        f32x4 da_acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         // weight fragments one hidden tile ahead; the scheduling barrier at the bottom of a tile keeps the compiler from
         // hoisting all TPW tiles' loads to the top (with the 2 TPW + TPW accumulator quads that would not fit 256 VGPRs)
         frag_t f1 = CmBuf<T>::gather(rsW1, vo1, hw * ES);
@@ -251,53 +260,69 @@ __global__ void __launch_bounds__(64 * CM_BW) chanmlp_bwd_kernel(CmBwdArgs g) {
             const frag_t f4 = CmBuf<T>::ld4(rsW1, vo4, h0 * ES);
             const frag_t f1n = CmBuf<T>::gather(rsW1, vo1, hn * ES);
             const f32x4 biasn = cm_ld_f32x4(rsb1, vob, hn * 4);
-            f32x4 h = bias;
-            mma16(h, f1, aB1);
-            f32x4 dg = f32x4{0.f, 0.f, 0.f, 0.f};
-            mma16(dg, f3, dyB1);
-            f32x4 gv, gp;
-            gelu_both4(h, gv, gp);
-            const f32x4 dh = dg * gp;
-            frag_t dhf;
-            make_frag(dhf, dh[0], dh[1], dh[2], dh[3]);
-            mma16(da_acc, f4, dhf);
-            // 16 x 16 transposes (wave-private LDS): written [hidden 4q+e][row r], read back [hidden r][rows 4q..4q+3]
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                trG[(4 * q + e) * CM_TLD + r] = gv[e];
-                trD[(4 * q + e) * CM_TLD + r] = dh[e];
+            for (int i = 0; i < RG; ++i) {
+                float* trG = &tr[w][2 * i][0];
+                float* trD = &tr[w][2 * i + 1][0];
+                f32x4 h = bias;
+                mma16(h, f1, aB1[i]);
+                f32x4 dg = f32x4{0.f, 0.f, 0.f, 0.f};
+                mma16(dg, f3, dyB1[i]);
+                f32x4 gv, gp;
+                gelu_both4(h, gv, gp);
+                const f32x4 dh = dg * gp;
+                frag_t dhf;
+                make_frag(dhf, dh[0], dh[1], dh[2], dh[3]);
+                mma16(da_acc[i], f4, dhf);
+                // 16 x 16 transposes (wave-private LDS): written [hidden 4q+e][row r], read back [hidden r][rows 4q..4q+3]
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    trG[(4 * q + e) * CM_TLD + r] = gv[e];
+                    trD[(4 * q + e) * CM_TLD + r] = dh[e];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const f32x4 gt = *reinterpret_cast<const f32x4*>(trG + r * CM_TLD + 4 * q);
+                const f32x4 dht = *reinterpret_cast<const f32x4*>(trD + r * CM_TLD + 4 * q);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const f32x4 a2v = *reinterpret_cast<const f32x4*>(&tr[w][2 * RG + 2 * i][0] + r * CM_TLD + 4 * q);
+                const f32x4 d2v = *reinterpret_cast<const f32x4*>(&tr[w][2 * RG + 2 * i + 1][0] + r * CM_TLD + 4 * q);
+                frag_t gtf, dhtf, aB2, dyB2;
+                make_frag(gtf, gt[0], gt[1], gt[2], gt[3]);
+                make_frag(dhtf, dht[0], dht[1], dht[2], dht[3]);
+                make_frag(aB2, a2v[0], a2v[1], a2v[2], a2v[3]);
+                make_frag(dyB2, d2v[0], d2v[1], d2v[2], d2v[3]);
+                mma16(dW2a[tt], gtf, dyB2);
+                mma16(dW1a[tt], dhtf, aB2);
+                dba[tt] += (dht[0] + dht[1]) + (dht[2] + dht[3]);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const f32x4 gt = *reinterpret_cast<const f32x4*>(trG + r * CM_TLD + 4 * q);
-            const f32x4 dht = *reinterpret_cast<const f32x4*>(trD + r * CM_TLD + 4 * q);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            frag_t gtf, dhtf;
-            make_frag(gtf, gt[0], gt[1], gt[2], gt[3]);
-            make_frag(dhtf, dht[0], dht[1], dht[2], dht[3]);
-            mma16(dW2a[tt], gtf, dyB2);
-            mma16(dW1a[tt], dhtf, aB2);
-            dba[tt] += (dht[0] + dht[1]) + (dht[2] + dht[3]);
             f1 = f1n; bias = biasn;
             __builtin_amdgcn_sched_barrier(0);
         }
-        // d a of this row tile: the waves' partial sums (each over its own hidden range), added in wave order
-        *reinterpret_cast<f32x4*>(&red[w][r * CM_C + 4 * q]) = da_acc;
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            const int rr = threadIdx.x >> 2, c4 = (threadIdx.x & 3) * 4;
-            f32x4 s = *reinterpret_cast<const f32x4*>(&red[0][rr * CM_C + c4]);
+        // d a of these row tiles: the waves' partial sums (each over its own hidden range), added in wave order.  One barrier
+        // per step: the partials alternate between two LDS slabs (a slab is rewritten two steps later, after the barrier of
+        // the step in between, which every wave reaches only after its reads), and every wave sums its share of the rows.
+        float* slab = &red[par][0][0];
 #pragma unroll
-            for (int k = 1; k < CM_BW; ++k) s += *reinterpret_cast<const f32x4*>(&red[k][rr * CM_C + c4]);
-            if (row0 + rr < g.rows) {
-                float* scr = g.dascr + (row0 + rr) * CM_C + c4;
+        for (int i = 0; i < RG; ++i)
+            *reinterpret_cast<f32x4*>(slab + (w * RG + i) * 256 + r * CM_C + 4 * q) = da_acc[i];
+        __syncthreads();
+        if (lane < 8 * RG) {
+            const int i = lane >> 3, l8 = lane & 7;
+            const int rr = 2 * w + (l8 >> 2), c4 = (l8 & 3) * 4;
+            const int64_t row = (rg * RG + i) * 16 + rr;
+            f32x4 s = *reinterpret_cast<const f32x4*>(slab + i * 256 + rr * CM_C + c4);
+#pragma unroll
+            for (int k = 1; k < CM_BW; ++k) s += *reinterpret_cast<const f32x4*>(slab + (k * RG + i) * 256 + rr * CM_C + c4);
+            if (row < g.rows) {
+                float* scr = g.dascr + row * CM_C + c4;
                 if (pass > 0) s += *reinterpret_cast<const f32x4*>(scr);
                 if (pass + 1 < g.npass) *reinterpret_cast<f32x4*>(scr) = s;
-                else CmIO<T>::st((T*)g.da + (row0 + rr) * CM_C + c4, s);
+                else CmIO<T>::st((T*)g.da + row * CM_C + c4, s);
             }
         }
-        __syncthreads();
+        par ^= 1;
     }
     // flush this pass's part of the workgroup's record: [dW1^T: H x 16][dW2: H x 16][db1: H]
 #pragma unroll
@@ -348,8 +373,9 @@ constexpr int CM_TPW_MAX = 8;    // hidden tiles per wave and pass (2 x 4 + 1 ac
 inline bool cm_h_ok(int64_t H) { return H == 128 || H == 256 || H == 512 || (H > 0 && H % 1024 == 0 && H <= 16384); }
 inline int cm_tpw(int64_t H) { const int64_t t = H / (16 * CM_BW); return (int)(t < CM_TPW_MAX ? t : CM_TPW_MAX); }
 inline int cm_npass(int64_t H) { return (int)(H / (16 * CM_BW * cm_tpw(H))); }
+constexpr int CM_RG = 2;         // reverse: 16-row tiles per step
 inline int cm_bwd_blocks(int64_t rows) {
-    const int64_t tiles = ceil_div64(rows, 16);
+    const int64_t tiles = ceil_div64(rows, 16 * CM_RG);
     return (int)(tiles < 256 ? tiles : 256);       // one 8-wave workgroup per CU
 }
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
