@@ -152,9 +152,9 @@ __global__ void __launch_bounds__(AT) adaln_bwd_mod_kernel(AdaArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Narrow rows (the Mixer: W = 16 channels per token, 10^5 rows): a whole workgroup per 64-byte row leaves 255 of 256
-// lanes idle.  Here a row is held by LPR = W * sizeof(T) / 16 lanes (one 16-byte piece each), a wave covers
-// 64 / LPR rows per step (fully coalesced), and the row reductions are LPR-lane butterflies.
+// Narrow rows (the Mixer: W = 16 channels per token, 10^5 rows; its encoder: 256 channels): a whole workgroup per 64-byte
+// row leaves 255 of 256 lanes idle.  Here a row (up to 1 KB) is held by LPR = W * sizeof(T) / 16 lanes (one 16-byte piece
+// each), a wave covers 64 / LPR rows per step (fully coalesced), and the row reductions are LPR-lane butterflies.
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T> struct Piece;
 template <> struct Piece<float> { static constexpr int VW = 4; typedef f32x4 vec; };
@@ -274,20 +274,35 @@ __global__ void __launch_bounds__(AT) adaln_bwd_mod_narrow_kernel(AdaArgs a, int
     float as[VW], ah[VW];
 #pragma unroll
     for (int i = 0; i < VW; ++i) { as[i] = 0.f; ah[i] = 0.f; }
-    for (int64_t row = r0 + slot; row < r1; row += nslot) {
-        float x[VW], dy[VW];
-        ld_piece<T>((const T*)a.x + row * a.ldx + part * VW, x);
-        ld_piece<T>((const T*)a.dy + row * a.ldy + part * VW, dy);
-        float mean, rho;
-        ln_stats<T>(x, lpr, invW, mean, rho);
+    // four independent rows per step: eight 16-byte loads in flight per lane (one row at a time, a group of 544 rows x 1 KB
+    // is a chain of 136 HBM round trips per wave); rows past the group load zeros and add nothing
+    constexpr int RU = 4;
+    for (int64_t row = r0 + slot; row < r1; row += RU * nslot) {
+        float x[RU][VW], dy[RU][VW];
 #pragma unroll
-        for (int i = 0; i < VW; ++i) { as[i] += dy[i] * ((x[i] - mean) * rho); ah[i] += dy[i]; }
+        for (int u = 0; u < RU; ++u) {
+            const int64_t rr = row + (int64_t)u * nslot;
+            if (rr < r1) {
+                ld_piece<T>((const T*)a.x + rr * a.ldx + part * VW, x[u]);
+                ld_piece<T>((const T*)a.dy + rr * a.ldy + part * VW, dy[u]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < VW; ++i) { x[u][i] = 0.f; dy[u][i] = 0.f; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            float mean, rho;
+            ln_stats<T>(x[u], lpr, invW, mean, rho);
+#pragma unroll
+            for (int i = 0; i < VW; ++i) { as[i] += dy[u][i] * ((x[u][i] - mean) * rho); ah[i] += dy[u][i]; }
+        }
     }
 #pragma unroll
     for (int i = 0; i < VW; ++i) { red[0][threadIdx.x * VW + i] = as[i]; red[1][threadIdx.x * VW + i] = ah[i]; }
     __syncthreads();
-    if (threadIdx.x < 2 * a.W) {
-        const int which = threadIdx.x >= a.W, c = threadIdx.x - which * (int)a.W;
+    for (int o = threadIdx.x; o < 2 * (int)a.W; o += AT) {
+        const int which = o >= a.W, c = o - which * (int)a.W;
         const int pc = c / VW, ic = c % VW;
         float sum = 0.f;
         for (int k = 0; k < nslot; ++k) sum += red[which][(k * lpr + pc) * VW + ic];
@@ -298,7 +313,7 @@ __global__ void __launch_bounds__(AT) adaln_bwd_mod_narrow_kernel(AdaArgs a, int
 inline bool narrow_ok(int dtype, int64_t W, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs, int& lpr) {
     const int64_t es = dtype == MFC_F32 ? 4 : 2;
     const int64_t bytes = W * es;
-    if (bytes % 16 || bytes > 256) return false;
+    if (bytes % 16 || bytes > 1024) return false;     // a row is held by at most one wave (64 lanes x 16 bytes)
     lpr = (int)(bytes / 16);
     if (lpr & (lpr - 1)) return false;
     for (int64_t ld : lds) if ((ld * es) % 16) return false;
@@ -438,7 +453,7 @@ extern "C" int mfc_adaln_bwd(int dtype, int64_t rows, int64_t W, const void* x, 
     int lpr = 0;
     // (mod_div == 1: dscale / dshift are [rows, W] in `dtype`; mod_div > 1: fp32 [groups, W] -- 16-byte pieces of fp32 need W % 4)
     if (rows >= 1024 && narrow_ok(dtype, W, {ldx, ldm, ldy, mod_div == 1 ? ldd : 0}, {x, scale, dy, dx, mod_div == 1 ? dscale : nullptr,
-                                  mod_div == 1 ? dshift : nullptr}, lpr) && 2 * W <= AT) {
+                                  mod_div == 1 ? dshift : nullptr}, lpr)) {
         const unsigned grid = grid1d(rows * lpr);
         if (dtype == MFC_F32) hipLaunchKernelGGL(adaln_bwd_narrow_kernel<float>, dim3(grid), dim3(AT), 0, st, a, lpr);
         else hipLaunchKernelGGL(adaln_bwd_narrow_kernel<u16>, dim3(grid), dim3(AT), 0, st, a, lpr);
