@@ -68,6 +68,24 @@ def auto_splitk(M: int, N: int, K: int) -> int:
     two workgroups per CU -- measured optimum at K = 392 704 and K = 6 270 016 (tools/sweep_splitk.py: 256..512 slices
     are 6-12 % faster than 1024, whose 64 MB of slabs per operand-GB start to show, and than 128, which starves HBM)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if 1024 <= K <= 8192 and tiles >= 16:
+        # Mid-size products (the Mixer's token mixing and projections, BASELINE config #3): a power-of-two slice count,
+        # slices at least 512 deep, chosen so that the workgroups fill the 256 CUs evenly -- at least two per CU and within
+        # 10 % of a whole number of rounds (tools/sweep_splitk_mixer.py: 3072 x 2048 x 1024 runs 9 % faster in 2 slices than
+        # in 1 = 384 workgroups = 1.5 rounds; 192 x 16384 x 1024, whose 64-row remainder is a launch of its own, 54 %).
+        ntn, mfull, rem = (N + 127) // 128, M // 128, M % 128
+        main = (mfull if (mfull >= 1 and 0 < rem <= 64) else (M + 127) // 128) * ntn     # workgroups of the main launch per slice
+        # (K = 1024 with the CUs already covered stays whole: measured inside the training step, 3072 x 2048 x 1024 is 10 %
+        # slower in two 512-deep slices although the isolated product is 9 % faster)
+        depth = 512 if (K >= 2048 or main < 256) else 1024
+        best, sk = 1, 1
+        while K // sk >= depth:
+            best = sk
+            W = main * sk
+            if W >= 512 and ((W + 255) // 256) * 256 <= 1.1 * W:
+                break
+            sk *= 2
+        return best
     if K < 512 or tiles >= 256:
         return 1
     if K < 2048:
