@@ -535,8 +535,10 @@ def gate_bwd(dy, o, s2, inv_k, ds2, do=None):
 
 
 def chanmlp_ok(C: int, H: int) -> bool:
-    """Shapes the fused channel MLP takes (forward and reverse): 16 channels, H in {128, 256, 512} or a multiple of 1024."""
-    return C == 16 and (H in (128, 256, 512) or (H > 0 and H % 1024 == 0 and H <= 16384))
+    """Shapes the fused channel MLP takes (forward and reverse): 16 channels and a hidden width the reverse kernel
+    accepts -- the library decides (``mfc_chanmlp_ws_elems`` returns MFC_ENOSYS otherwise: H in {128, 256, 512} or a
+    multiple of 1024)."""
+    return C == 16 and H > 0 and int(_lib.lib().mfc_chanmlp_ws_elems(16, int(H))) > 0
 
 
 def chanmlp_fwd(a, W1, b1, W2, b2, act_rows=None, residual=None, out=None):
