@@ -325,11 +325,16 @@ gemm_kernel(GemmArgs g) {
     const bool do_colsum = CAN_COLSUM && g.colsum != nullptr && m0 == 0 && blockIdx.z == 0;
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+#ifndef MFC_GEMM_ABL
+#define MFC_GEMM_ABL 0      // profiling ablations (compile-time; results are wrong by design): 1 = no global loads in the K loop,
+#endif                      // 2 = also no LDS stores, 4 = no barriers in the K loop
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-        SA::store(As, ra);
-        SB::store(Bs, rb);
-        __syncthreads();
-        if (k0 + BK < kend) {   // next tile's global loads fly during the MFMAs
+        if (!(MFC_GEMM_ABL & 2) || k0 == kbeg) {
+            SA::store(As, ra);
+            SB::store(Bs, rb);
+        }
+        if (!(MFC_GEMM_ABL & 4) || k0 == kbeg) __syncthreads();
+        if (k0 + BK < kend && !(MFC_GEMM_ABL & 1)) {   // next tile's global loads fly during the MFMAs
             SA::load(A, g.lda, m0, g.M, k0 + BK, kend, g.vecA, ra);
             SB::load(B, g.ldb, n0, g.N, k0 + BK, kend, g.vecB, rb);
         }
@@ -358,7 +363,7 @@ gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mma16(acc[i][j], af[i], bf[j]);
         }
-        __syncthreads();
+        if (!(MFC_GEMM_ABL & 4)) __syncthreads();
     }
 
     if constexpr (CAN_COLSUM) {
