@@ -52,7 +52,15 @@ struct GemmArgs {
     // -- the bias gradient that belongs to this weight gradient (B = dY): the operand is in LDS anyway, so the separate
     // pass over dY (1.6 GB for the [128, S] kernels) disappears.  Written by the workgroups of the first M tile only.
     float* colsum; float colsum_scale;
+    // fp32 fast staging (gemm_kernel<.., FAST>): byte sizes of the A / B operands for their buffer resources
+    uint32_t a_bytes, b_bytes;
+    int fast;
 };
+
+// raw buffer resource (base, num_records bytes): out-of-range lanes load 0 / drop their store in hardware
+__device__ inline __amdgpu_buffer_rsrc_t gemm_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
 
 template <typename T> struct Vec;   // 16-byte global vector
 template <> struct Vec<float> { typedef f32x4 type; static constexpr int W = 4; };
@@ -104,6 +112,32 @@ template <typename T, int BK, bool KC, int ROWS = 128> struct Stage {
             for (int p = 0; p < NPT; ++p) {
                 const int64_t k = k0 + kk + KPP * p, row = row0 + rr;
                 regs[p] = (kk + KPP * p < BK && k < kend && row < nrows) ? loadv<T>(src + k * ld + row, nrows - row, vec) : z;
+            }
+        }
+    }
+    // Branch-free staging through a buffer resource over the whole operand (fp32 compute-bound products whose K range is
+    // whole K-steps): every vector is one unconditional 16-byte buffer load -- the thread's part of the address is one
+    // loop-invariant VGPR, the step's part a scalar offset.  Rows past the operand's last row load zeros (or, on the
+    // contiguous axis of a row-contiguous operand, the neighbouring row's finite values): they only feed rows / columns of C
+    // that are never stored.  The guarded form above costs these kernels ~13 % of their time.
+    __device__ static inline void load_buf(__amdgpu_buffer_rsrc_t rs, int64_t ld, int64_t row0, int64_t k0, vec_t* regs) {
+        const int t = threadIdx.x;
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        if constexpr (KC) {
+            const int kk = (t % TPR) * W, rr = t / TPR;
+            const uint32_t voff = (uint32_t)((rr * ld + kk) * sizeof(T));
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const uint32_t soff = (uint32_t)(((row0 + RPP * p) * ld + k0) * sizeof(T));
+                regs[p] = __builtin_bit_cast(vec_t, (u32x4_)__builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+            }
+        } else {
+            const int rr = (t % TPK) * W, kk = t / TPK;
+            const uint32_t voff = (uint32_t)((kk * ld + rr) * sizeof(T));
+#pragma unroll
+            for (int p = 0; p < NPT; ++p) {
+                const uint32_t soff = (uint32_t)(((k0 + KPP * p) * ld + row0) * sizeof(T));
+                regs[p] = __builtin_bit_cast(vec_t, (u32x4_)__builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
             }
         }
     }
@@ -279,9 +313,8 @@ __device__ inline void ln16_tangent_lane(float xd[16], const float n[16], float 
     }
 }
 
-template <typename T, int BK, bool TA, bool TB, int BMT>
-__global__ void __launch_bounds__(GT)
-gemm_kernel(GemmArgs g) {
+template <typename T, int BK, bool TA, bool TB, int BMT, bool FAST>
+__device__ __forceinline__ void gemm_body(GemmArgs g) {
     constexpr int MI = BMT / 32;          // 16-row MFMA tiles per wave along M (waves are 2 x 2)
     // operand tiles: [128][LDK] when the source is K-contiguous, [BK][LDR] when it is row-contiguous
     constexpr int TEA = tile_elems(BK, sizeof(T), BMT > 128 ? BMT : 128), TE = tile_elems(BK, sizeof(T));
@@ -316,8 +349,13 @@ gemm_kernel(GemmArgs g) {
 
     typename SA::vec_t ra[SA::NV];
     typename SB::vec_t rb[SB::NV];
-    SA::load(A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
-    SB::load(B, g.ldb, n0, g.N, kbeg, kend, g.vecB, rb);
+    if constexpr (FAST) {
+        SA::load_buf(gemm_rsrc(g.A, g.a_bytes), g.lda, m0, kbeg, ra);
+        SB::load_buf(gemm_rsrc(g.B, g.b_bytes), g.ldb, n0, kbeg, rb);
+    } else {
+        SA::load(A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
+        SB::load(B, g.ldb, n0, g.N, kbeg, kend, g.vecB, rb);
+    }
 
     // column sums of the B tile (bias gradient, see GemmArgs::colsum): thread (kg, cg) adds k-rows 4 kg .. 4 kg + 3 of
     // columns 8 cg .. 8 cg + 7 of every K-step; only bf16, row-contiguous B ([BK][LDR] image), first M tile
@@ -335,8 +373,13 @@ gemm_kernel(GemmArgs g) {
         }
         if (!(MFC_GEMM_ABL & 4) || k0 == kbeg) __syncthreads();
         if (k0 + BK < kend && !(MFC_GEMM_ABL & 1)) {   // next tile's global loads fly during the MFMAs
-            SA::load(A, g.lda, m0, g.M, k0 + BK, kend, g.vecA, ra);
-            SB::load(B, g.ldb, n0, g.N, k0 + BK, kend, g.vecB, rb);
+            if constexpr (FAST) {
+                SA::load_buf(gemm_rsrc(g.A, g.a_bytes), g.lda, m0, k0 + BK, ra);
+                SB::load_buf(gemm_rsrc(g.B, g.b_bytes), g.ldb, n0, k0 + BK, rb);
+            } else {
+                SA::load(A, g.lda, m0, g.M, k0 + BK, kend, g.vecA, ra);
+                SB::load(B, g.ldb, n0, g.N, k0 + BK, kend, g.vecB, rb);
+            }
         }
         if constexpr (CAN_COLSUM) {
             if (do_colsum) {       // (rows past kend were staged as zeros)
@@ -468,6 +511,18 @@ gemm_kernel(GemmArgs g) {
             }
         }
     }
+}
+
+template <typename T, int BK, bool TA, bool TB, int BMT>
+__global__ void __launch_bounds__(GT)
+gemm_kernel(GemmArgs g) {
+    gemm_body<T, BK, TA, TB, BMT, false>(g);
+}
+// the same tile loop with branch-free buffer-resource staging (fp32 compute-bound products, see Stage::load_buf)
+template <bool TA, bool TB, int BMT>
+__global__ void __launch_bounds__(GT)
+gemm_f32_fast_kernel(GemmArgs g) {
+    gemm_body<float, 64, TA, TB, BMT, true>(g);
 }
 
 // ---------------------------------------------------------------------------
@@ -831,6 +886,15 @@ gemm_epilogue_kernel(const float* ws, int nslab, int64_t M, int64_t N, T* C, int
 
 template <typename T, int BK, int BMT>
 void launch_bk(bool ta, bool tb, dim3 grid, const GemmArgs& g, hipStream_t st) {
+    if constexpr (sizeof(T) == 4 && BK == 64 && BMT <= 128) {
+        if (g.fast) {      // fp32, whole K-steps, operands below 4 GiB: branch-free staging
+            if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_fast_kernel<false, false, BMT>), grid, dim3(GT), 0, st, g);
+            else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_fast_kernel<false, true, BMT>), grid, dim3(GT), 0, st, g);
+            else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_fast_kernel<true, false, BMT>), grid, dim3(GT), 0, st, g);
+            else hipLaunchKernelGGL((gemm_f32_fast_kernel<true, true, BMT>), grid, dim3(GT), 0, st, g);
+            return;
+        }
+    }
     if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, BK, false, false, BMT>), grid, dim3(GT), 0, st, g);
     else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, BK, false, true, BMT>), grid, dim3(GT), 0, st, g);
     else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, BK, true, false, BMT>), grid, dim3(GT), 0, st, g);
@@ -980,6 +1044,15 @@ int gemm_impl(int dtype, int flags, int64_t M, int64_t N, int64_t K, const void*
     // 16-byte vector loads need every row start 16-byte aligned
     g.vecA = (((lda * es) % 16) == 0) && (((uintptr_t)A % 16) == 0);
     g.vecB = (((ldb * es) % 16) == 0) && (((uintptr_t)B % 16) == 0);
+    {
+        // operand extents in bytes ([rows][ld] with the last row only as wide as it is used)
+        const int64_t a_rows = ta ? K : M, a_cols = ta ? M : K, b_rows = tb ? N : K, b_cols = tb ? K : N;
+        const int64_t ab = ((a_rows - 1) * lda + a_cols) * es, bb = ((b_rows - 1) * ldb + b_cols) * es;
+        g.fast = dtype == MFC_F32 && !opt && g.vecA && g.vecB && K > 32 && K % 64 == 0 && ab < (1LL << 32) && bb < (1LL << 32) &&
+                 ((M > N ? (M > K ? M : K) : (N > K ? N : K)) + 192) * (lda > ldb ? lda : ldb) * (int64_t)es < (1LL << 32);   // 32-bit offsets
+        g.a_bytes = (uint32_t)(g.fast ? ab : 0);
+        g.b_bytes = (uint32_t)(g.fast ? bb : 0);
+    }
     g.vecC = (N % 16 == 0) && ((ldc * es) % 16 == 0) && (((uintptr_t)C % 16) == 0) &&
              (!R || (((ldr * es) % 16 == 0) && (((uintptr_t)R % 16) == 0)));
     g.opt_p = g.opt_m = g.opt_v = nullptr;
