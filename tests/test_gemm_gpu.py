@@ -42,6 +42,40 @@ def test_gemm_all_layouts(dtype, ta, tb):
         assert err <= tol, (M, N, K, ta, tb, dtype, err, scale)
 
 
+FAST_SHAPES = [(130, 260, 128), (37, 516, 1024), (300, 64, 4096), (1, 4, 64), (129, 132, 192), (192, 160, 64),
+               (448, 48, 256), (200, 40, 640), (256, 384, 128), (65, 1040, 832)]
+
+
+@pytest.mark.parametrize("ta,tb", list(itertools.product([False, True], repeat=2)))
+def test_gemm_f32_whole_ksteps_fast_staging(ta, tb):
+    """fp32 products whose K is a whole number of 64-deep steps and whose operands are 16-byte aligned take the branch-free
+    buffer-resource staging (gemm_f32_fast_kernel): ragged M / N tiles (rows past the operand read zeros or a neighbour's
+    values and must not reach C), strided operands whose padding holds NaN, split-K, accumulate -- against fp64."""
+    from meanflow_audio_codec_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for (M, N, K) in FAST_SHAPES:
+        ash, bsh = ((K, M) if ta else (M, K)), ((N, K) if tb else (K, N))
+        # operands are views into NaN-filled buffers with a wider (16-byte aligned) leading dimension
+        Abig = torch.full((ash[0], ash[1] + 8), float("nan"), device="cuda")
+        Bbig = torch.full((bsh[0], bsh[1] + 12), float("nan"), device="cuda")
+        A, B = Abig[:, :ash[1]], Bbig[:, :bsh[1]]
+        A.copy_(torch.randn(ash, generator=g, device="cuda"))
+        B.copy_(torch.randn(bsh, generator=g, device="cuda"))
+        bias = torch.randn(N, generator=g, device="cuda")
+        R = torch.randn(M, N, generator=g, device="cuda")
+        ref = _ref(A, B, ta, tb, bias, max(1, M // 2), 0.5, R, 2.0)
+        for sk in (1, 2) if K >= 256 else (1,):
+            C = ops.gemm(A, B, trans_a=ta, trans_b=tb, bias=bias, bias_rows=max(1, M // 2), alpha=0.5, residual=R, beta=2.0,
+                         splitk=sk)
+            assert torch.isfinite(C).all(), (M, N, K, ta, tb, sk)
+            err = (C.double() - ref).abs().max().item()
+            assert err <= 1e-5 * max(ref.abs().max().item(), 1.0), (M, N, K, ta, tb, sk, err)
+        C0 = torch.randn(M, N, generator=g, device="cuda")
+        C1 = ops.gemm(A, B, trans_a=ta, trans_b=tb, out=C0.clone(), accumulate=True)
+        ref1 = (A.t() if ta else A).double() @ (B.t() if tb else B).double() + C0.double()
+        assert (C1.double() - ref1).abs().max().item() <= 1e-5 * max(ref1.abs().max().item(), 1.0), (M, N, K, ta, tb)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_splitk_gelu_tangent_rows(dtype):
     """Row-stacked [x; xdot]: primal rows get bias + GELU, tangent rows t*gelu'(pre)."""
