@@ -42,6 +42,11 @@ def test_no_vector_spills_and_no_scratch_in_bf16_kernels(res):
     ("gemm_kernel<unsigned short, 64, false, false, 192>", 256),
     ("gemm_nstream_kernel<3, false>", 256), ("gemm_nstream_kernel<1, false>", 128), ("gemm_nstream_kernel<2, true>", 168),
     ("m512::mdct512_fwd_kernel<true, 5>", 128), ("m512::mdct512_inv_kernel<true>", 168),
+    # BASELINE config #3: fused channel MLP (forward: four 4-wave workgroups per CU; reverse: one 8-wave workgroup) and the
+    # fp32 tiled GEMM with branch-free staging (two workgroups per CU)
+    ("chanmlp_fwd_kernel<float>", 128), ("chanmlp_bwd_kernel<float, 8, 2>", 256), ("chanmlp_bwd_kernel<unsigned short, 8, 2>", 256),
+    ("gemm_f32_fast_kernel<false, false, 128>", 256), ("gemm_f32_fast_kernel<true, false, 128>", 256),
+    ("gemm_f32_fast_kernel<false, true, 128>", 256),
 ])
 def test_occupancy_tier_of_the_hot_kernels(res, kernel, max_vgpr):
     assert kernel in res, sorted(res)[:5]
