@@ -38,7 +38,7 @@ def _stale(out: pathlib.Path, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = True, jobs: int = 4) -> pathlib.Path:
     hipcc = _hipcc()
-    headers = list(CSRC.glob("*.h")) + list((CSRC.parents[1] / "include").glob("*.h"))
+    headers = list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + list((CSRC.parents[1] / "include").glob("*.h"))
     objs = []
     todo = []
     for src in sources():

@@ -52,10 +52,10 @@ struct GemmArgs {
     // -- the bias gradient that belongs to this weight gradient (B = dY): the operand is in LDS anyway, so the separate
     // pass over dY (1.6 GB for the [128, S] kernels) disappears.  Written by the workgroups of the first M tile only.
     float* colsum; float colsum_scale;
-    // fp32 fast staging (gemm_kernel<.., FAST>): byte sizes of the A / B operands for their buffer resources
-    uint32_t a_bytes, b_bytes;
-    int fast;
 };
+// fp32 fast staging (gemm_f32_fast_kernel): byte sizes of the A / B operands for their buffer resources; separate kernel
+// arguments, so that the argument block of every other kernel stays as it was (the bf16 kernels sit at the SGPR / VGPR edge)
+struct GemmFast { uint32_t a_bytes, b_bytes; int on; };
 
 // raw buffer resource (base, num_records bytes): out-of-range lanes load 0 / drop their store in hardware
 __device__ inline __amdgpu_buffer_rsrc_t gemm_rsrc(const void* base, uint32_t bytes) {
@@ -313,216 +313,21 @@ __device__ inline void ln16_tangent_lane(float xd[16], const float n[16], float 
     }
 }
 
-template <typename T, int BK, bool TA, bool TB, int BMT, bool FAST>
-__device__ __forceinline__ void gemm_body(GemmArgs g) {
-    constexpr int MI = BMT / 32;          // 16-row MFMA tiles per wave along M (waves are 2 x 2)
-    // operand tiles: [128][LDK] when the source is K-contiguous, [BK][LDR] when it is row-contiguous
-    constexpr int TEA = tile_elems(BK, sizeof(T), BMT > 128 ? BMT : 128), TE = tile_elems(BK, sizeof(T));
-#ifndef MFC_GEMM_LDS_PAD
-#define MFC_GEMM_LDS_PAD 0     // occupancy probe (compile-time): unused extra LDS bytes per workgroup
-#endif
-    __shared__ __attribute__((aligned(16))) T lds[TEA + TE + MFC_GEMM_LDS_PAD / sizeof(T)];
-    T* As = lds;
-    T* Bs = lds + TEA;
-    typedef typename Frag<T>::type frag_t;
-    typedef Stage<T, BK, !TA, BMT> SA;   // A: K-contiguous when not transposed ([M][K])
-    typedef Stage<T, BK, TB> SB;    // B: K-contiguous when transposed ([N][K])
-
-    const T* A = (const T*)g.A;
-    const T* B = (const T*)g.B;
-    // M-tile index fastest when it fits: the M-tiles of one N-tile run back to back, so the streamed
-    // weight tile is fetched from HBM once and re-read from L2 / Infinity Cache
-    const int64_t m0 = g.m_base + (int64_t)(g.m_fast ? blockIdx.x : blockIdx.y) * BMT;
-    const int64_t n0 = (int64_t)(g.m_fast ? blockIdx.y : blockIdx.x) * BN;
-    const int64_t kbeg = (int64_t)blockIdx.z * g.kchunk;
-    const int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * (BMT / 2), wn = (wave & 1) * 64;
-    const int q = lane >> 4, r = lane & 15;
-
-    f32x4 acc[MI][4];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    typename SA::vec_t ra[SA::NV];
-    typename SB::vec_t rb[SB::NV];
-    if constexpr (FAST) {
-        SA::load_buf(gemm_rsrc(g.A, g.a_bytes), g.lda, m0, kbeg, ra);
-        SB::load_buf(gemm_rsrc(g.B, g.b_bytes), g.ldb, n0, kbeg, rb);
-    } else {
-        SA::load(A, g.lda, m0, g.M, kbeg, kend, g.vecA, ra);
-        SB::load(B, g.ldb, n0, g.N, kbeg, kend, g.vecB, rb);
-    }
-
-    // column sums of the B tile (bias gradient, see GemmArgs::colsum): thread (kg, cg) adds k-rows 4 kg .. 4 kg + 3 of
-    // columns 8 cg .. 8 cg + 7 of every K-step; only bf16, row-contiguous B ([BK][LDR] image), first M tile
-    constexpr bool CAN_COLSUM = sizeof(T) == 2 && !TB && BK == 64;
-    const bool do_colsum = CAN_COLSUM && g.colsum != nullptr && m0 == 0 && blockIdx.z == 0;
-    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-#ifndef MFC_GEMM_ABL
-#define MFC_GEMM_ABL 0      // profiling ablations (compile-time; results are wrong by design): 1 = no global loads in the K loop,
-#endif                      // 2 = also no LDS stores, 4 = no barriers in the K loop
-    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-        if (!(MFC_GEMM_ABL & 2) || k0 == kbeg) {
-            SA::store(As, ra);
-            SB::store(Bs, rb);
-        }
-        if (!(MFC_GEMM_ABL & 4) || k0 == kbeg) __syncthreads();
-        if (k0 + BK < kend && !(MFC_GEMM_ABL & 1)) {   // next tile's global loads fly during the MFMAs
-            if constexpr (FAST) {
-                SA::load_buf(gemm_rsrc(g.A, g.a_bytes), g.lda, m0, k0 + BK, ra);
-                SB::load_buf(gemm_rsrc(g.B, g.b_bytes), g.ldb, n0, k0 + BK, rb);
-            } else {
-                SA::load(A, g.lda, m0, g.M, k0 + BK, kend, g.vecA, ra);
-                SB::load(B, g.ldb, n0, g.N, k0 + BK, kend, g.vecB, rb);
-            }
-        }
-        if constexpr (CAN_COLSUM) {
-            if (do_colsum) {       // (rows past kend were staged as zeros)
-                const int cg = threadIdx.x & 15, kg = threadIdx.x >> 4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const s16x8 v = *reinterpret_cast<const s16x8*>(Bs + (4 * kg + i) * SB::LDR + 8 * cg);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) csum[e] += bf16_to_f32((u16)v[e]);
-                }
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < BK / 16; ++c) {
-            frag_t af[MI], bf[4];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                af[i] = SA::fetch(As, wm + 16 * i, c, q, r);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                bf[j] = SB::fetch(Bs, wn + 16 * j, c, q, r);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mma16(acc[i][j], af[i], bf[j]);
-        }
-        if (!(MFC_GEMM_ABL & 4)) __syncthreads();
-    }
-
-    if constexpr (CAN_COLSUM) {
-        if (do_colsum) {
-            // fixed order: the 4 k-groups of a wave by two shuffles, then the 4 waves through LDS (the operand tiles are
-            // free: the K loop ended on a barrier)
-            float* red = reinterpret_cast<float*>(lds);          // [4 waves][128 columns]
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float v = csum[e];
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
-                csum[e] = v;
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) red[wave * 128 + 8 * lane + e] = csum[e];
-            }
-            __syncthreads();
-            if (threadIdx.x < 128 && n0 + threadIdx.x < g.N) {
-                const int c = threadIdx.x;
-                g.colsum[n0 + c] = g.colsum_scale * (((red[c] + red[128 + c]) + red[256 + c]) + red[384 + c]);
-            }
-            __syncthreads();
-        }
-    }
-
-    // epilogue.  C layout of a 16x16 MFMA tile: col = lane&15, row = 4*(lane>>4)+reg
-    T* C = (T*)g.C;
-    const T* R = (const T*)g.R;
-    if (!g.ws && g.vecC) {
-        // Row-contiguous stores: each wave transposes its 64x64 result 16 rows at a time through a
-        // private LDS slab so every lane writes 16 consecutive columns (32/64 B) of one row --
-        // 16x fewer (and full-line) store instructions than storing the MFMA C layout directly.
-        constexpr int CSS = 68;
-        float* cs = reinterpret_cast<float*>(lds) + wave * (16 * CSS);
-        const int lr = lane >> 2, lc = (lane & 3) * 16;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) cs[(4 * q + e) * CSS + 16 * j + r] = acc[i][j][e];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int64_t row = m0 + wm + 16 * i + lr;
-            if (g.opt_p) {    // mfc_gemm_adamw: see adamw_tile_16x64 for the lane -> (row, column) mapping
-                float gv[16];
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(cs + (4 * k4 + (lane >> 4)) * CSS + 4 * (lane & 15));
-                    gv[4 * k4] = t[0] * g.alpha; gv[4 * k4 + 1] = t[1] * g.alpha; gv[4 * k4 + 2] = t[2] * g.alpha; gv[4 * k4 + 3] = t[3] * g.alpha;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const int64_t row0 = m0 + wm + 16 * i, col0 = n0 + wn;
-                if (row0 + 16 <= g.M && col0 + 64 <= g.N) adamw_tile_16x64<T, false>(g, row0, col0, lane, gv);   // wave-uniform
-                else adamw_tile_16x64<T, true>(g, row0, col0, lane, gv);
-                continue;
-            }
-            const int64_t col0 = n0 + wn + lc;
-            float v[16];
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(cs + lr * CSS + lc + 4 * k4);
-                v[4 * k4] = t[0]; v[4 * k4 + 1] = t[1]; v[4 * k4 + 2] = t[2]; v[4 * k4 + 3] = t[3];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (row < g.M && col0 < g.N) {
-                const bool hb = g.bias && row < g.bias_rows;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] = (v[k] + (hb ? g.bias[col0 + k] : 0.f)) * g.alpha;
-                if (g.ln_rstd && row < g.bias_rows) {
-                    // fused first LayerNorm of the ConvNeXt block: this lane holds one pixel's 16 channels
-                    g.ln_rstd[row * (g.N >> 4) + (col0 >> 4)] = ln16_lane(v);
-                }
-                store_row16<T>(g, row, col0, v);
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t col = n0 + wn + 16 * j + r;
-            if (col >= g.N) continue;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t row = m0 + wm + 16 * i + 4 * q + e;
-                if (row >= g.M) continue;
-                float v = acc[i][j][e];
-                if (g.ws) {
-                    // split-K: slice z owns slab z of the workspace (plain stores; the epilogue sums the slabs in
-                    // slice order, so the result does not depend on the order workgroups finish in)
-                    g.ws[(int64_t)blockIdx.z * g.ws_slab + row * g.N + col] = v;
-                } else {
-                    if (g.bias && row < g.bias_rows) v += g.bias[col];
-                    v *= g.alpha;
-                    if (R) v += g.beta * St<T>::ld(R + row * g.ldr + col);
-                    if (g.accum) v += St<T>::ld(C + row * g.ldc + col);
-                    St<T>::st(C + row * g.ldc + col, v);
-                }
-            }
-        }
-    }
-}
-
 template <typename T, int BK, bool TA, bool TB, int BMT>
 __global__ void __launch_bounds__(GT)
 gemm_kernel(GemmArgs g) {
-    gemm_body<T, BK, TA, TB, BMT, false>(g);
+    constexpr bool FAST = false;
+    constexpr uint32_t a_bytes = 0u, b_bytes = 0u;
+#include "gemm_tile_body.inc"
 }
 // the same tile loop with branch-free buffer-resource staging (fp32 compute-bound products, see Stage::load_buf)
 template <bool TA, bool TB, int BMT>
 __global__ void __launch_bounds__(GT)
-gemm_f32_fast_kernel(GemmArgs g) {
-    gemm_body<float, 64, TA, TB, BMT, true>(g);
+gemm_f32_fast_kernel(GemmArgs g, uint32_t a_bytes, uint32_t b_bytes) {
+    typedef float T;
+    constexpr int BK = 64;
+    constexpr bool FAST = true;
+#include "gemm_tile_body.inc"
 }
 
 // ---------------------------------------------------------------------------
@@ -885,13 +690,13 @@ gemm_epilogue_kernel(const float* ws, int nslab, int64_t M, int64_t N, T* C, int
 }
 
 template <typename T, int BK, int BMT>
-void launch_bk(bool ta, bool tb, dim3 grid, const GemmArgs& g, hipStream_t st) {
+void launch_bk(bool ta, bool tb, dim3 grid, const GemmArgs& g, const GemmFast& f, hipStream_t st) {
     if constexpr (sizeof(T) == 4 && BK == 64 && BMT <= 128) {
-        if (g.fast) {      // fp32, whole K-steps, operands below 4 GiB: branch-free staging
-            if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_fast_kernel<false, false, BMT>), grid, dim3(GT), 0, st, g);
-            else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_fast_kernel<false, true, BMT>), grid, dim3(GT), 0, st, g);
-            else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_fast_kernel<true, false, BMT>), grid, dim3(GT), 0, st, g);
-            else hipLaunchKernelGGL((gemm_f32_fast_kernel<true, true, BMT>), grid, dim3(GT), 0, st, g);
+        if (f.on) {      // fp32, whole K-steps, operands below 4 GiB: branch-free staging
+            if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_fast_kernel<false, false, BMT>), grid, dim3(GT), 0, st, g, f.a_bytes, f.b_bytes);
+            else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_fast_kernel<false, true, BMT>), grid, dim3(GT), 0, st, g, f.a_bytes, f.b_bytes);
+            else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_fast_kernel<true, false, BMT>), grid, dim3(GT), 0, st, g, f.a_bytes, f.b_bytes);
+            else hipLaunchKernelGGL((gemm_f32_fast_kernel<true, true, BMT>), grid, dim3(GT), 0, st, g, f.a_bytes, f.b_bytes);
             return;
         }
     }
@@ -903,7 +708,7 @@ void launch_bk(bool ta, bool tb, dim3 grid, const GemmArgs& g, hipStream_t st) {
 
 // one launch over rows [m_base, m_base + rows) with BMT-row tiles
 template <typename T, int BMT>
-int launch_rows(int flags, GemmArgs g, int bk, int splitk, int64_t m_base, int64_t rows, hipStream_t st) {
+int launch_rows(int flags, GemmArgs g, const GemmFast& f, int bk, int splitk, int64_t m_base, int64_t rows, hipStream_t st) {
     const int64_t tm = ceil_div64(rows, BMT), tn = ceil_div64(g.N, BN);
     g.m_base = m_base;
     g.M = m_base + rows;          // rows >= M are masked; rows < m_base are never touched by this launch
@@ -911,13 +716,13 @@ int launch_rows(int flags, GemmArgs g, int bk, int splitk, int64_t m_base, int64
     if (!g.m_fast && tm > 65535) return MFC_EINVAL;
     dim3 grid((unsigned)(g.m_fast ? tm : tn), (unsigned)(g.m_fast ? tn : tm), (unsigned)splitk);
     const bool ta = flags & MFC_GEMM_TRANS_A, tb = flags & MFC_GEMM_TRANS_B;
-    if (bk == 32) launch_bk<T, 32, BMT>(ta, tb, grid, g, st);
-    else launch_bk<T, 64, BMT>(ta, tb, grid, g, st);
+    if (bk == 32) launch_bk<T, 32, BMT>(ta, tb, grid, g, f, st);
+    else launch_bk<T, 64, BMT>(ta, tb, grid, g, f, st);
     return mfc_launch_status();
 }
 
 template <typename T>
-int launch(int flags, GemmArgs g, int bk, int splitk, int gelu, int64_t act_rows, hipStream_t st) {
+int launch(int flags, GemmArgs g, const GemmFast& f, int bk, int splitk, int gelu, int64_t act_rows, hipStream_t st) {
     // 128-row tiles for the bulk; a remainder of <= 64 rows (row-stacked [primal; tangent] batches such as
     // 128 + 64) runs as a second launch with 64-row tiles instead of a half-empty 128-row tile
     const int64_t M = g.M;
@@ -926,12 +731,12 @@ int launch(int flags, GemmArgs g, int bk, int splitk, int gelu, int64_t act_rows
     static const int bm192 = getenv("MFC_GEMM_BM192") ? atoi(getenv("MFC_GEMM_BM192")) : 1;
     if (bm192 && M > 128 && M <= 192 && sizeof(T) == 2) {
         // 128 + <= 64 row-stacked rows in ONE 192-row tile: the streamed operand is read once, not once per launch
-        rc = launch_rows<T, 192>(flags, g, bk, splitk, 0, M, st);
+        rc = launch_rows<T, 192>(flags, g, f, bk, splitk, 0, M, st);
     } else if (tail > 0 && tail <= 64) {
-        if (M > tail) rc = launch_rows<T, 128>(flags, g, bk, splitk, 0, M - tail, st);
-        if (!rc) rc = launch_rows<T, 64>(flags, g, bk, splitk, M - tail, tail, st);
+        if (M > tail) rc = launch_rows<T, 128>(flags, g, f, bk, splitk, 0, M - tail, st);
+        if (!rc) rc = launch_rows<T, 64>(flags, g, f, bk, splitk, M - tail, tail, st);
     } else {
-        rc = launch_rows<T, 128>(flags, g, bk, splitk, 0, M, st);
+        rc = launch_rows<T, 128>(flags, g, f, bk, splitk, 0, M, st);
     }
     g.M = M;
     if (rc) return rc;
@@ -1044,14 +849,15 @@ int gemm_impl(int dtype, int flags, int64_t M, int64_t N, int64_t K, const void*
     // 16-byte vector loads need every row start 16-byte aligned
     g.vecA = (((lda * es) % 16) == 0) && (((uintptr_t)A % 16) == 0);
     g.vecB = (((ldb * es) % 16) == 0) && (((uintptr_t)B % 16) == 0);
+    GemmFast fast = {0u, 0u, 0};
     {
         // operand extents in bytes ([rows][ld] with the last row only as wide as it is used)
         const int64_t a_rows = ta ? K : M, a_cols = ta ? M : K, b_rows = tb ? N : K, b_cols = tb ? K : N;
         const int64_t ab = ((a_rows - 1) * lda + a_cols) * es, bb = ((b_rows - 1) * ldb + b_cols) * es;
-        g.fast = dtype == MFC_F32 && !opt && g.vecA && g.vecB && K > 32 && K % 64 == 0 && ab < (1LL << 32) && bb < (1LL << 32) &&
+        fast.on = dtype == MFC_F32 && !opt && g.vecA && g.vecB && K > 32 && K % 64 == 0 && ab < (1LL << 32) && bb < (1LL << 32) &&
                  ((M > N ? (M > K ? M : K) : (N > K ? N : K)) + 192) * (lda > ldb ? lda : ldb) * (int64_t)es < (1LL << 32);   // 32-bit offsets
-        g.a_bytes = (uint32_t)(g.fast ? ab : 0);
-        g.b_bytes = (uint32_t)(g.fast ? bb : 0);
+        fast.a_bytes = (uint32_t)(fast.on ? ab : 0);
+        fast.b_bytes = (uint32_t)(fast.on ? bb : 0);
     }
     g.vecC = (N % 16 == 0) && ((ldc * es) % 16 == 0) && (((uintptr_t)C % 16) == 0) &&
              (!R || (((ldr * es) % 16 == 0) && (((uintptr_t)R % 16) == 0)));
@@ -1097,8 +903,8 @@ int gemm_impl(int dtype, int flags, int64_t M, int64_t N, int64_t K, const void*
         }
     }
     g.ws_slab = M * N;     // every (row < M, col < N) of every slab is written by exactly one workgroup: no memset
-    int rc = dtype == MFC_F32 ? launch<float>(flags, g, bk, splitk, gelu, act_rows, st)
-                              : launch<u16>(flags, g, bk, splitk, gelu, act_rows, st);
+    int rc = dtype == MFC_F32 ? launch<float>(flags, g, fast, bk, splitk, gelu, act_rows, st)
+                              : launch<u16>(flags, g, fast, bk, splitk, gelu, act_rows, st);
     if (!rc && ln_tan) {
         const int64_t rows = M - bias_rows, groups = N >> 4;
         int64_t blocks = ceil_div64(rows * groups, 256);
