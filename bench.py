@@ -220,10 +220,11 @@ def symbol_of(name, ints, nn):
         if dt == 1 and not (flags & 1) and K == 128 and M <= 256 and not (flags & 8):
             # A in registers, B streamed: NN (forward products) or NT (dX against a [N, 128] kernel; no bias / LayerNorm)
             return f"gemm_nstream_kernel<{(((M + 15) // 16) + 3) // 4}, {tf(flags & 2)}>"   # 16-row tiles per wave
-        if dt == 0 and K > 32 and K % 64 == 0:
-            # fp32 products over whole K-steps (16-byte aligned operands below 4 GiB, as every call here is): the branch-free
-            # staging variant of the same tile loop (csrc/gemm.hip: gemm_f32_fast_kernel)
-            return f"gemm_f32_fast_kernel<{tf(flags & 1)}, {tf(flags & 2)}, {128 if M > 64 else 64}>"
+        if K > 32 and K % 64 == 0:
+            # products over whole K-steps (16-byte aligned operands below 4 GiB, as every call here is): the branch-free
+            # staging variant of the same tile loop (csrc/gemm.hip: gemm_f32_fast_kernel / gemm_bf16_fast_kernel)
+            bm = 64 if M <= 64 else (192 if (dt == 1 and 128 < M <= 192) else 128)
+            return f"gemm_{'f32' if dt == 0 else 'bf16'}_fast_kernel<{tf(flags & 1)}, {tf(flags & 2)}, {bm}>"
         return f"gemm_kernel<{T}, {32 if K <= 32 else 64}, {tf(flags & 1)}, {tf(flags & 2)}, {128 if M > 64 else 64}>"
     if name.startswith("mfc_cnx_"):
         T = "float" if ints[0] == 0 else "unsigned short"

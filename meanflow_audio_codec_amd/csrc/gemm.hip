@@ -329,6 +329,16 @@ gemm_f32_fast_kernel(GemmArgs g, uint32_t a_bytes, uint32_t b_bytes) {
     constexpr bool FAST = true;
 #include "gemm_tile_body.inc"
 }
+// the same for the bf16 products without an optimizer epilogue (the K = S / K = D products of the ConvFlow block and, in the
+// data-parallel schedule, the un-fused weight gradients: 3-8 % on those HBM-bound launches, tools/bench_gemm.py)
+template <bool TA, bool TB, int BMT>
+__global__ void __launch_bounds__(GT)
+gemm_bf16_fast_kernel(GemmArgs g, uint32_t a_bytes, uint32_t b_bytes) {
+    typedef u16 T;
+    constexpr int BK = 64;
+    constexpr bool FAST = true;
+#include "gemm_tile_body.inc"
+}
 
 // ---------------------------------------------------------------------------
 // N-streaming variant for the skinny products of the ConvNeXt flow (bf16, NN, K = 128, M <= 256,
@@ -700,6 +710,15 @@ void launch_bk(bool ta, bool tb, dim3 grid, const GemmArgs& g, const GemmFast& f
             return;
         }
     }
+    if constexpr (sizeof(T) == 2 && BK == 64) {
+        if (f.on) {
+            if (!ta && !tb) hipLaunchKernelGGL((gemm_bf16_fast_kernel<false, false, BMT>), grid, dim3(GT), 0, st, g, f.a_bytes, f.b_bytes);
+            else if (!ta && tb) hipLaunchKernelGGL((gemm_bf16_fast_kernel<false, true, BMT>), grid, dim3(GT), 0, st, g, f.a_bytes, f.b_bytes);
+            else if (ta && !tb) hipLaunchKernelGGL((gemm_bf16_fast_kernel<true, false, BMT>), grid, dim3(GT), 0, st, g, f.a_bytes, f.b_bytes);
+            else hipLaunchKernelGGL((gemm_bf16_fast_kernel<true, true, BMT>), grid, dim3(GT), 0, st, g, f.a_bytes, f.b_bytes);
+            return;
+        }
+    }
     if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, BK, false, false, BMT>), grid, dim3(GT), 0, st, g);
     else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, BK, false, true, BMT>), grid, dim3(GT), 0, st, g);
     else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, BK, true, false, BMT>), grid, dim3(GT), 0, st, g);
@@ -854,8 +873,10 @@ int gemm_impl(int dtype, int flags, int64_t M, int64_t N, int64_t K, const void*
         // operand extents in bytes ([rows][ld] with the last row only as wide as it is used)
         const int64_t a_rows = ta ? K : M, a_cols = ta ? M : K, b_rows = tb ? N : K, b_cols = tb ? K : N;
         const int64_t ab = ((a_rows - 1) * lda + a_cols) * es, bb = ((b_rows - 1) * ldb + b_cols) * es;
-        fast.on = dtype == MFC_F32 && !opt && g.vecA && g.vecB && K > 32 && K % 64 == 0 && ab < (1LL << 32) && bb < (1LL << 32) &&
-                 ((M > N ? (M > K ? M : K) : (N > K ? N : K)) + 192) * (lda > ldb ? lda : ldb) * (int64_t)es < (1LL << 32);   // 32-bit offsets
+        // 32-bit offsets: the slow axis of an operand is walked in tiles of 64 / 128 / 192 rows (M, N) or in whole K-steps
+        const int64_t oa = (ta ? K : ceil_div64(M, 64) * 64) * lda * (int64_t)es, ob = (tb ? ceil_div64(N, 128) * 128 : K) * ldb * (int64_t)es;
+        fast.on = !opt && g.vecA && g.vecB && K > 32 && K % 64 == 0 && ab < (1LL << 32) && bb < (1LL << 32) &&
+                  oa < (1LL << 32) && ob < (1LL << 32);
         fast.a_bytes = (uint32_t)(fast.on ? ab : 0);
         fast.b_bytes = (uint32_t)(fast.on ? bb : 0);
     }

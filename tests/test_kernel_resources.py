@@ -47,6 +47,10 @@ def test_no_vector_spills_and_no_scratch_in_bf16_kernels(res):
     ("chanmlp_fwd_kernel<float>", 128), ("chanmlp_bwd_kernel<float, 8, 2>", 256), ("chanmlp_bwd_kernel<unsigned short, 8, 2>", 256),
     ("gemm_f32_fast_kernel<false, false, 128>", 256), ("gemm_f32_fast_kernel<true, false, 128>", 256),
     ("gemm_f32_fast_kernel<false, true, 128>", 256),
+    # the bf16 products without an optimizer epilogue (K = S / K = D products; un-fused weight gradients of the DP schedule)
+    ("gemm_bf16_fast_kernel<false, false, 192>", 256), ("gemm_bf16_fast_kernel<false, false, 128>", 168),
+    ("gemm_bf16_fast_kernel<false, true, 128>", 168), ("gemm_bf16_fast_kernel<true, false, 128>", 168),
+    ("gemm_bf16_fast_kernel<false, false, 64>", 128),
 ])
 def test_occupancy_tier_of_the_hot_kernels(res, kernel, max_vgpr):
     assert kernel in res, sorted(res)[:5]
