@@ -247,7 +247,7 @@ def symbol_of(name, ints, nn):
         return f"chanmlp_fwd_kernel<{'float' if ints[0] == 0 else 'unsigned short'}>"
     if name == "mfc_chanmlp_bwd":
         H = ints[2]
-        return f"chanmlp_bwd_kernel<{'float' if ints[0] == 0 else 'unsigned short'}, {min(8, H // 128)}>"
+        return f"chanmlp_bwd_kernel<{'float' if ints[0] == 0 else 'unsigned short'}, {min(8, H // 128)}, 2>"
     return name.replace("mfc_", "") + "_kernel"
 
 
