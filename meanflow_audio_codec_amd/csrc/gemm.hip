@@ -354,6 +354,17 @@ __device__ inline void mma32(f32x4& acc, const s16x8& a, const s16x8& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
 }
 constexpr int NS_BN = 64, NS_K = 128, NS_KS = NS_K / 16, NS_LDR = 80, NS_MAXT = 4;
+#ifndef MFC_NS_CT
+#define MFC_NS_CT 1
+#endif
+#ifndef MFC_NS_SWZ
+#define MFC_NS_SWZ 1
+#endif
+// NN weight tile in LDS.  MFC_NS_SWZ: [128 k][64 n] rows of 128 bytes without padding, the 8-byte piece p of row k kept at
+// piece p ^ ((k >> 1) & 3): the 32 lanes ds_read_b64_tr_b16 serves per LDS cycle (8 k-rows x 4 pieces 32 bytes apart) then
+// start on 32 different bank pairs.  The padded image (rows of 160 bytes) put them on 8: four cycles per half instead of one
+// (SQ_LDS_BANK_CONFLICT: 200 of ~260 LDS cycles per wave and 64-column step).
+constexpr int NS_LDB = MFC_NS_SWZ ? NS_BN : NS_LDR;
 struct NsPlan {
     // per wave: up to 4 16-row tiles of C, processed in order; kind 0 = plain, 1 = LN16 primal,
     // 2 = LN16 tangent of the entry before it
@@ -380,8 +391,12 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     typedef u16 T;
     typedef Frag<T>::type frag_t;
     constexpr int NS_LDN = NS_K + 8;        // NT: [64 n][128 k] rows padded by 16 bytes
-    __shared__ __attribute__((aligned(16))) T Bs[NT ? NS_BN * NS_LDN : NS_K * NS_LDR];
+    __shared__ __attribute__((aligned(16))) T Bs[NT ? NS_BN * NS_LDN : NS_K * NS_LDB];
     __shared__ __attribute__((aligned(16))) float bias_s[NS_BN];
+#if MFC_NS_CT
+    constexpr int NS_LDC = NS_BN + 8;       // wave-private image of a 16 x 64 C tile, rows padded by 16 bytes
+    __shared__ __attribute__((aligned(16))) T Cs[4 * 16 * NS_LDC];
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, r = lane & 15;
@@ -432,9 +447,30 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     const int k0 = NT ? (ch0 >> 4) : (ch0 >> 3), c80 = NT ? (ch0 & 15) * 8 : (ch0 & 7) * 8;   // NT: k0 = the tile row n
     const uint32_t boff0 = (uint32_t)((k0 * g.ldb + c80) * 2);
     const uint32_t bstep = (uint32_t)((NT ? 16 : 32) * g.ldb * 2);          // rows per chunk index p: 256 threads / chunks per row
-    constexpr int LDS_PSTEP = NT ? 16 * NS_LDN : 32 * NS_LDR;
-    const int lds_off0 = k0 * (NT ? NS_LDN : NS_LDR) + c80;
+    constexpr int LDS_PSTEP = NT ? 16 * NS_LDN : 32 * NS_LDB;
+    const int lds_off0 = k0 * (NT ? NS_LDN : NS_LDB) + c80;
+    constexpr bool SWZ = !NT && MFC_NS_SWZ;
+    // swizzled image: the chunk's two 8-byte pieces 2 (ch0 & 7) + h go to pieces (2 (ch0 & 7) + h) ^ g of their row, g = (k0 >> 1) & 3
+    // (rows 32 apart share g)
+    const int lds_sw = k0 * NS_LDB + 4 * ((2 * (ch0 & 7)) ^ ((k0 >> 1) & 3));
     u32x4 rb[4];
+    auto commit_b = [&]() {
+        // (the second piece's offset is recomputed here, from a copy the compiler cannot fold: one address register live
+        // across the loop instead of two -- the M = 192 instantiation sits at its 168-register edge)
+        int lds_sw0 = lds_sw;
+        asm volatile("" : "+v"(lds_sw0));
+        const int lds_sw1 = lds_sw0 ^ 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if constexpr (SWZ) {
+                typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2_t*>(Bs + lds_sw0 + p * LDS_PSTEP) = u32x2_t{rb[p][0], rb[p][1]};
+                *reinterpret_cast<u32x2_t*>(Bs + lds_sw1 + p * LDS_PSTEP) = u32x2_t{rb[p][2], rb[p][3]};
+            } else {
+                *reinterpret_cast<u32x4*>(Bs + lds_off0 + p * LDS_PSTEP) = rb[p];
+            }
+        }
+    };
     auto load_b = [&](int64_t tile) {
         const int64_t n0 = tile * NS_BN;
         // NN: columns >= N of rows < K-1 alias the next row (finite weights, results never stored); the last row is clipped.
@@ -450,6 +486,7 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     // 16 (rho >> 2) + 4 j + (rho & 3): lane (q, r) then ends up with C[row r][16 q .. 16 q + 15] of the 64-column
     // tile in acc[.][j][e] -- a whole LayerNorm group and one 32-byte store per lane, with no LDS transpose.
     const int lr = r, lc = 16 * q;
+    const int rd_sw = (4 * q + (r >> 2)) * NS_LDB + 16 * (r & 3) + 4 * ((2 * q + (r >> 3)) & 3);   // element offset of piece 4 (r & 3) + (0 ^ g)
     const bool has_alpha = g.alpha != 1.0f;
     const __amdgpu_buffer_rsrc_t rs_bias = make_rsrc(g.bias, g.bias ? (uint32_t)(N * 4) : 0u);
     // Loop shape: the B tile of iteration t+1 is requested at the top of iteration t and committed to LDS at its
@@ -459,8 +496,7 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
     int64_t tile = blockIdx.x;
     if (tile < ntiles) {
         load_b(tile);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs + lds_off0 + p * LDS_PSTEP) = rb[p];
+        commit_b();
     }
     __syncthreads();
     for (; tile < ntiles; tile += gridDim.x) {
@@ -484,6 +520,8 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
 #pragma unroll
         for (int c = 0; c < NS_KS / 2; ++c) {
             frag8_t bf[4];
+            int rd_c = rd_sw;       // (a copy per k-step the compiler cannot fold: the four piece offsets rd_c ^ 4 j live for one step)
+            if constexpr (SWZ) asm volatile("" : "+v"(rd_c));
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if constexpr (NT) {
@@ -492,9 +530,11 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
                     bf[j] = *reinterpret_cast<const frag8_t*>(Bs + (16 * (r >> 2) + 4 * j + (r & 3)) * NS_LDN + 32 * c + 8 * q);
                 } else {
                     // LDS transpose reads: lane 4q'+p of group q supplies k-row 4q+q', columns 16p + 4j .. +3
-                    const T* bp = Bs + (32 * c + 4 * q + (r >> 2)) * NS_LDR + 16 * (r & 3) + 4 * j;
+                    // (swizzled: piece 4 (r & 3) + j of row k sits at piece (4 (r & 3) + j) ^ g(k); g does not depend on c or on the +16 rows)
+                    const T* bp = SWZ ? Bs + (32 * c) * NS_LDB + (rd_c ^ (4 * j))
+                                      : Bs + (32 * c + 4 * q + (r >> 2)) * NS_LDB + 16 * (r & 3) + 4 * j;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp + 16 * NS_LDR));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp + 16 * NS_LDB));
                     bf[j] = frag8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
             }
@@ -582,16 +622,42 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
                     }
                 }
             }
+#if MFC_NS_CT
+            {
+                // a lane holds 32 bytes of ONE row (16 rows per 16 lanes): stored like that, every store instruction is 64
+                // separate 16-byte pieces for L2 to merge.  Through a wave-private LDS image the same tile leaves as two
+                // instructions of eight whole 128-byte lines each (8 lanes per line).
+                T* cw = Cs + wave * (16 * NS_LDC);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x4 t = {pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                                     pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+                    *reinterpret_cast<u32x4*>(cw + lr * NS_LDC + lc + 8 * h) = t;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int64_t ccol = tile * NS_BN + 8 * (lane & 7);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = (lane >> 3) + 8 * h;
+                    const u32x4 t = *reinterpret_cast<const u32x4*>(cw + row * NS_LDC + 8 * (lane & 7));
+                    __builtin_amdgcn_raw_buffer_store_b128(t, rs_c, ccol < N ? (uint32_t)((row * g.ldc + ccol) * 2) : NS_OOB, 0, 0);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+#else
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const u32x4 t = {pack_bf16x2(v[8 * h], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
                                  pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
                 __builtin_amdgcn_raw_buffer_store_b128(t, rs_c, coff + 16 * h, 0, 0);
             }
+#endif
         }
         // commit the prefetched B tile (every wave left the MFMA loop at the barrier above)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(Bs + lds_off0 + p * LDS_PSTEP) = rb[p];
+        commit_b();
         __syncthreads();
     }
 }
