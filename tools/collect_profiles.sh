@@ -14,4 +14,5 @@ for w in mnist_mlp mnist_mixer mdct; do cp $S/bench_$w.json $D/${TAG}_bench_$w.j
 for w in mnist_mlp mnist_mixer; do cp $(ls $S/stats_$w/*/*kernel_stats.csv | head -1) $D/${TAG}_${w}_rocprofv3_kernel_stats.csv; done
 cp $S/${TAG}_mixer_sq_counters.json $D/${TAG}_mixer_sq_counters.json
 cp $R/gpurun_out/${TAG}_cnx_sq/${TAG}_cnx_sq_counters.json $D/${TAG}_cnx_sq_counters.json
+cp $S/${TAG}_nstream_sq_counters.json $D/${TAG}_nstream_sq_counters.json; cp $S/${TAG}_nstream_lds_counters.txt $D/${TAG}_nstream_lds_counters.txt
 ls -la $D | grep $TAG

@@ -44,6 +44,13 @@ timeout -k 10 300 rocprofv3 --pmc $CNT -d "$OUT/sq_mixer" --output-format csv --
     > "$OUT/sq_mixer.json" 2> "$OUT/sq_mixer.log" || exit 10
 python3 "$R/tools/sq_counters.py" "$OUT/sq_mixer" "$OUT/${TAG}_mixer_sq_counters.json" "^(gemm|adaln|gelu|colsum|transpose|chanmlp)" > "$OUT/sq_mixer_reduce.log" 2>&1 || exit 11
 echo "[profile] small-workload profiles done"
+# SQ counters (issue / wait split, LDS bank conflicts) of the N-streaming GEMM on its micro-benchmark
+timeout -k 10 200 rocprofv3 --pmc $CNT -d "$OUT/sq_nstream" --output-format csv -- python3 "$R/tools/bench_nstream.py" > "$OUT/sq_nstream.log" 2>&1 || exit 13
+python3 "$R/tools/sq_counters.py" "$OUT/sq_nstream" "$OUT/${TAG}_nstream_sq_counters.json" "^gemm_nstream" > "$OUT/sq_nstream_reduce.log" 2>&1 || exit 14
+timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR \
+    -d "$OUT/sq_nstream_lds" --output-format csv -- python3 "$R/tools/bench_nstream.py" > "$OUT/sq_nstream_lds.log" 2>&1 || exit 15
+python3 "$R/tools/pmc_sum.py" "$OUT/sq_nstream_lds" gemm_nstream > "$OUT/${TAG}_nstream_lds_counters.txt" 2>&1 || exit 16
+echo "[profile] N-streaming counters done"
 cd "$R" || exit 9
 tools/profile_cnx_sq.sh "$TAG" > "$OUT/cnx_sq.log" 2>&1 || exit 12
 find "$OUT" "$R/gpurun_out/${TAG}_cnx_sq" -name "*kernel_trace.csv" -size +20M -delete
