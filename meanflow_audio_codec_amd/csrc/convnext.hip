@@ -280,6 +280,15 @@ __device__ inline TileCoord tile_next(const Geo& g, TileCoord c) {
 // ---------------------------------------------------------------------------
 __device__ uint4 g_zero16;   // 16 zero bytes: DMA source of halo pixels outside the image
 
+// MFC_CNX_DRAIN=1 (default): the tile kernels wait for EVERYTHING they have in flight (vmcnt(0)) before the barrier that hands a
+// DMA buffer over.  MFC_CNX_DRAIN=0 counts the stores issued after the request instead (vmcnt(S_VMEM)), which by the in-order rule
+// of the counter should be equivalent -- but with it 6 of ~330 evaluations of the literal-size loss + reverse pass were not
+// bitwise repeatable (one traced to this file's conv-gradient kernel: dh0 differed while every reduction agreed, i.e. the
+// youngest DMA, the 1/sigma dwords, had not landed), against 0 of 120 with the full wait; the full wait costs <= 1.5 % of
+// these kernels.
+#ifndef MFC_CNX_DRAIN
+#define MFC_CNX_DRAIN 1
+#endif
 typedef __attribute__((address_space(1))) void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -903,7 +912,7 @@ cnx_fwd_kernel(FwdArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         // this wave's share of tile t+1 has landed once at most the S_VMEM stores issued after the request are pending
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_VMEM) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MFC_CNX_DRAIN ? 0 : S_VMEM) : "memory");
     }
     if (rcur >= 0) flush_stats(rcur);
 }
@@ -1156,7 +1165,7 @@ cnx_bwd_kernel(BwdArgs a) {
             for (int ri = nrows; ri < RPW; ++ri) buf_st4(rs_dc, BUF_OOB, zv, (const T*)nullptr);
         }
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_VMEM) : "memory");   // this wave's share of tile t+1 has landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MFC_CNX_DRAIN ? 0 : S_VMEM) : "memory");   // this wave's share of tile t+1 has landed
     }
     if (rcur >= 0) flush_row(rcur);
     if constexpr (MODE == 1) {
@@ -1436,7 +1445,7 @@ cnx_bwd_conv_kernel(BwdArgs a) {
             for (int ri = nrows; ri < RPW; ++ri) buf_st4(rs_dh, BUF_OOB, zv, (const T*)nullptr);
         }
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_VMEM) : "memory");   // this wave's share of tile t+1 has landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MFC_CNX_DRAIN ? 0 : S_VMEM) : "memory");   // this wave's share of tile t+1 has landed
     }
     float* scratch = (float*)const_cast<T*>(l.tile(1, 0));   // (flush_row's first barrier: every wave is past its last dc1 read)
     if (rcur >= 0) flush_row(rcur, scratch);

@@ -636,6 +636,9 @@ gemm_nstream_kernel(GemmArgs g, NsPlan plan, int64_t ntiles) {
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+#if MFC_NS_CT >= 2
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the image is complete before any lane reads it back
+#endif
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const int64_t ccol = tile * NS_BN + 8 * (lane & 7);
 #pragma unroll

@@ -138,6 +138,25 @@ def test_gelu_colsum_axpby_cast():
     assert torch.equal(ops.cast(a.bfloat16(), torch.float32), a.bfloat16().float())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_axpby_vector_path_equals_scalar_path(dtype):
+    """mfc_axpby takes 16 bytes per thread when n is a multiple of the vector width and the pointers are 16-byte aligned, the
+    one-element kernel otherwise (a view one element into the buffer): same arithmetic per element, so the same bits."""
+    from meanflow_audio_codec_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n = 8 * 12345
+    xa = torch.randn(n + 8, generator=g).to(dtype).cuda()
+    ya = torch.randn(n + 8, generator=g).to(dtype).cuda()
+    vec = ops.axpby(1.5, xa[:n], -0.25, ya[:n])                    # aligned, n % 8 == 0: vector kernel
+    sca = ops.axpby(1.5, xa[1:n], -0.25, ya[1:n])                  # unaligned views of n - 1 elements: scalar kernel
+    ref = 1.5 * xa[:n].float() - 0.25 * ya[:n].float()
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    assert (vec.float() - ref).abs().max() < tol
+    assert torch.equal(vec[1:], sca)
+    only_x = ops.axpby(-2.0, xa[:n])
+    assert torch.equal(only_x, (-2.0 * xa[:n].float()).to(dtype))
+
+
 @pytest.mark.parametrize("n", [5000, 5003, 3])
 def test_adamw_matches_oracle(n):
     """4-wide vector path, its < 4 element scalar tail, and the all-scalar path."""
