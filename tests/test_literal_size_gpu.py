@@ -111,6 +111,13 @@ def test_literal_shape_shards_sum_to_global_batch(literal_state):
     assert loss_again.item() == loss_full.item()
     assert fp_again == fp_full
     assert all(torch.equal(small_again[k], small_full[k]) for k in small_full)
+    # ... and six more times: the one non-repeatable evaluation ever seen here (round 3: a counted LDS-DMA wait in the ConvNeXt
+    # tile kernels) showed up in about one evaluation of fifty; tools/probe_step_determinism.py is the long screen
+    for _ in range(6):
+        loss_k, grads_k = strat.compute_loss(state, PRNGKey(0), x, e=e, t=t, r=r)
+        fp_k, small_k = fingerprint(grads_k)
+        assert loss_k.item() == loss_full.item() and fp_k == fp_full
+        assert all(torch.equal(small_k[k], small_full[k]) for k in small_full)
     acc = {k: 0.0 for k in big}
     small_acc = {k: torch.zeros_like(v) for k, v in small_full.items()}
     loss_sum = 0.0
